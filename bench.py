@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec (+ denoise-step ms) for Flux-schnell 512x512 2-step on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` — for N > 1 launched through
+torch.distributed.run, one rank per GPU.  A "step" is ONE pass of the hot path over one batch of
+synthetic input on every rank: B images/GPU x (2 denoise steps [Flux forward + Euler] + VAE decode),
+inputs (x_T, txt, vec) already resident in HBM.  Weak scaling: every rank generates its own images,
+no data-path collective; the only collective is the timing barrier/max.
+
+The JSON line also carries
+  roofline     — the dominant kernel (the 128x128 bf16 MFMA GEMM tile config): algorithmic FLOPs of
+                 its launches / their HIP-event time, measured live here, vs the dense bf16 MFMA peak;
+  cpu_baseline — the CPU oracle (a port; the reference's MLX cannot run here) timed on the host
+                 cores on a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flux_forward_flops(L: int, S: int, D: int = 3072, depth: int = 19, singles: int = 38) -> float:
+    """Algorithmic FLOPs (2*MAC) of one Flux forward per image."""
+    T = L + S
+    per_tok = 2 * D * (3 * D + D + 2 * 4 * D)          # qkv + proj + mlp (= 226.5 MFLOP at D=3072)
+    attn = 4 * T * T * D
+    f = depth * (per_tok * T + attn + 2 * 2 * D * 6 * D) + singles * (per_tok * T + attn + 2 * D * 3 * D)
+    return f + 2 * (64 * L + 4096 * S) * D + 2 * 64 * L * D
+
+
+def cpu_baseline_sample(T: int, threads: int) -> dict:
+    """Oracle (port) on the host cores: 1 double + 2 single blocks at full Flux width, T tokens,
+    bf16-representable weights, fp32 math; extrapolated to 2 x (19 double + 38 single) per image."""
+    from oracle import flux_oracle as O
+    torch.set_num_threads(threads)
+    P = O.FluxParams(depth=1, depth_single_blocks=1)
+    shapes = {k: v for k, v in O.flux_weight_shapes(P).items() if k.startswith(("double_blocks.0", "single_blocks.0"))}
+    W = O.init_weights(shapes, seed=0)
+    g = torch.Generator().manual_seed(0)
+    S = 256
+    img, txt = torch.randn(1, T - S, 3072, generator=g), torch.randn(1, S, 3072, generator=g)
+    vec = torch.randn(1, 3072, generator=g)
+    ids = torch.zeros(1, T, 3, dtype=torch.int32)
+    pe = O.embed_nd(ids, P.axes_dim, P.theta)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        i2, t2 = O.double_stream_block(W, "double_blocks.0", 24, img, txt, vec, pe)
+        t_double = time.perf_counter() - t0
+        x = torch.cat([t2, i2], dim=1)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            x = O.single_stream_block(W, "single_blocks.0", 24, x, vec, pe)
+        t_single = (time.perf_counter() - t0) / 2
+    per_image = 2 * (19 * t_double + 38 * t_single)
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32: 1 DoubleStreamBlock ({t_double:.2f} s) + 2 SingleStreamBlock ({t_single:.2f} s each) "
+                      f"at full width, T={T}; extrapolated to 2 steps x (19+38) blocks, VAE decode excluded"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--image-size", type=int, default=512)
+    ap.add_argument("--denoise-steps", type=int, default=2)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-only", action="store_true", help="run a few steps for rocprofv3, print nothing else")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from flux_generator_amd.flux.flux import FluxPipeline
+    import warnings
+    warnings.simplefilter("ignore")
+    pipe = FluxPipeline("flux-schnell", device=str(dev), use_graph=not args.no_graph)
+
+    B = args.batch
+    lat = args.image_size // 8
+    L, S = (lat // 2) ** 2, 256
+    # synthetic conditioning, resident in HBM before the timed region
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x_T = torch.randn(B, lat, lat, 16, generator=g, device=dev).to(torch.bfloat16)
+    txt = (torch.randn(B, S, 4096, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    vec = torch.randn(B, 768, generator=g, device=dev).to(torch.bfloat16)
+    txt_ids = torch.zeros(B, S, 3, dtype=torch.int32, device=dev)
+
+    def one_pass():
+        x, x_ids = pipe._prepare_latent_images(x_T)
+        for x in pipe._denoising_loop(x, x_ids, txt, txt_ids, vec, num_steps=args.denoise_steps, guidance=4.0):
+            pass
+        return pipe.decode(x, (lat, lat))
+
+    def sync_all():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        img = one_pass()
+    if args.profile_only:
+        for _ in range(args.steps):
+            one_pass()
+        torch.cuda.synchronize()
+        return
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = one_pass()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert img.shape == (B, args.image_size, args.image_size, 3) and bool(torch.isfinite(img).all())
+
+    # ---- denoise-step latency (one Flux forward + Euler) with HIP events on the launch stream
+    x, x_ids = pipe._prepare_latent_images(x_T)
+    tvec = torch.full((B,), 1.0, dtype=torch.bfloat16, device=dev)
+    gvec = torch.full((B,), 4.0, dtype=torch.bfloat16, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        pred = pipe._flow_step(x, x_ids, txt, txt_ids, vec, tvec, gvec)
+        pipe.sampler.step(pred, x, 1.0, 0.5)
+    e1.record()
+    torch.cuda.synchronize()
+    step_ms = e0.elapsed_time(e1) / reps
+    e0.record()
+    for _ in range(reps):
+        pipe.decode(x, (lat, lat))
+    e1.record()
+    torch.cuda.synchronize()
+    decode_ms = e0.elapsed_time(e1) / reps
+
+    # ---- roofline of the dominant kernel: per-launch HIP events over one eager pass of the plan
+    ws = pipe.flow._workspace(B, S, L)
+    recs = pipe.flow.profile_plan(ws)
+    recs = pipe.flow.profile_plan(ws)
+    by = {}
+    for label, ms, fl in recs:
+        a = by.setdefault(label, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += fl
+    dom = max(by, key=lambda k: by[k][1])
+    n, ms, fl = by[dom]
+    ach = fl / (ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": dom, "launches_per_forward": n, "avg_launch_ms": ms / n,
+                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": None}
+    breakdown = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": (round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None)}
+                 for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
+
+    if rank == 0:
+        total_images = world * args.steps * B
+        fwd_tflop = flux_forward_flops(L, S) / 1e12
+        out = {
+            "metric": "images/sec, Flux-schnell 512x512 2-step (denoise-step ms in config)",
+            "value": total_images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Flux-schnell {args.image_size}x{args.image_size} {args.denoise_steps}-step, "
+                                   f"batch {B}/GPU, random-init weights, synthetic x_T/txt/vec resident in HBM; "
+                                   "per step: 2 x (Flux forward + Euler) + VAE decode",
+                       "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
+                       "denoise_step_ms": step_ms, "vae_decode_ms": decode_ms,
+                       "flux_forward_tflop": fwd_tflop, "denoise_mfma_frac": fwd_tflop / (step_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
+                       "hip_graph": not args.no_graph, "kernel_breakdown_one_forward": breakdown},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_sample(L + S, torch.get_num_threads())
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

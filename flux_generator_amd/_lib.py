@@ -1,0 +1,89 @@
+"""ctypes binding of libfluxhip.so (C ABI declared in include/fluxhip.h).
+
+There is no fallback: if the shared library is missing or was not built for gfx950 the import of
+any op raises.  The product path never routes through PyTorch math or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("FLUXHIP_LIB", _HERE / "lib" / "libfluxhip.so"))
+
+c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class GemmGroup(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p),
+        ("res", c_void_p), ("gate", c_void_p),
+        ("a_bstride", c_int64), ("c_bstride", c_int64), ("gate_bstride", c_int64),
+        ("M", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("g", GemmGroup * 2),
+        ("ngroups", C.c_int32), ("nbatch", C.c_int32),
+        ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldc", C.c_int32),
+        ("epi", C.c_int32), ("row_bias", C.c_int32),
+        ("n_split", C.c_int32), ("ldc2", C.c_int32),
+        ("C2", c_void_p), ("c2_bstride", c_int64),
+        ("c2_coloff", C.c_int32), ("tile_cfg", C.c_int32),
+        ("alpha", c_float), ("out_f32", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/fluxhip.h declares
+SIGNATURES = {
+    "fluxhip_abi_version": (c_int, []),
+    "fluxhip_arch": (C.c_char_p, []),
+    "fluxhip_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
+    "fluxhip_gemm_tile_cfg": (c_int, [C.POINTER(GemmDesc)]),
+    "fluxhip_gemm_tile_shape": (c_int, [c_int, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),
+    "fluxhip_conv2d_bf16": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p]),
+    "fluxhip_conv2d_small": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
+    "fluxhip_small_linear_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "fluxhip_ln_modulate_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "fluxhip_qk_norm_rope_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_float, c_void_p]),
+    "fluxhip_attention_d128_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
+    "fluxhip_timestep_embedding_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
+    "fluxhip_rope_table_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "fluxhip_euler_step_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "fluxhip_pack_latents_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "fluxhip_unpack_latents_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "fluxhip_groupnorm_silu_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_void_p, c_int64, c_void_p]),
+    "fluxhip_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libfluxhip.so and bind every declared symbol. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"libfluxhip.so not found at {LIB_PATH}. Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or flux_generator_amd/csrc/build.sh. "
+            "There is no CPU / PyTorch fallback for the denoise path.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fluxhip_abi_version() != 1:
+        raise RuntimeError("libfluxhip ABI version mismatch")
+    if lib.fluxhip_arch() != b"gfx950":
+        raise RuntimeError("libfluxhip was not built for gfx950")
+    _lib = lib
+    return lib

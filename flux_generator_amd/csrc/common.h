@@ -1,0 +1,72 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libfluxhip.
+// Wavefront = 64 lanes everywhere in this tree; nothing here is portable to
+// 32-wide hardware and nothing tries to be.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in memory
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define FLUXHIP_OK 0
+#define FLUXHIP_EINVAL (-1)
+#define FLUXHIP_ELAUNCH (-2)
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+DEVINL float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+DEVINL float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// round-to-nearest-even f32 -> bf16 (v_cvt_pk_bf16_f32 on gfx950)
+DEVINL uint32_t pack_bf16x2(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<uint32_t*>(&r);
+}
+DEVINL bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+// value of f after a round trip through bf16 storage (MLX op-boundary rounding)
+DEVINL float rbf(float f) { return bf2f(f2bf(f)); }
+
+DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// GELU, tanh approximation: 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
+DEVINL float gelu_tanh_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  // tanh(u) = 1 - 2/(exp(2u)+1); saturates cleanly for |u| large
+  float e = __expf(2.0f * u);
+  float t = 1.0f - 2.0f / (e + 1.0f);
+  return 0.5f * x * (1.0f + t);
+}
+// exact (erf) GELU, used by the SD UNet GEGLU
+DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
+DEVINL float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+DEVINL float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// 16-byte async copy global -> LDS. LDS destination = wave-uniform base + lane*16.
+DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+DEVINL void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

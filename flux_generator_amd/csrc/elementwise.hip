@@ -1,0 +1,280 @@
+// Small memory-bound kernels around the denoise / decode path.
+#include "../../include/fluxhip.h"
+#include "common.h"
+
+namespace {
+
+// FluxSampler.step (flux/sampler.py:56-57): x + (t_prev - t) * pred, bf16 tensors, python-float dt.
+// MLX op boundaries: dt*pred -> bf16, sum -> bf16.
+__global__ __launch_bounds__(256) void euler_kernel(const bf16_t* __restrict__ x,
+                                                    const bf16_t* __restrict__ pred,
+                                                    bf16_t* __restrict__ out, long long n8,
+                                                    long long n, float dt) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n8) {
+    u32x4 a = *((const u32x4*)x + i), p = *((const u32x4*)pred + i), o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack_bf16x2(bf_lo(a[e]) + rbf(dt * bf_lo(p[e])), bf_hi(a[e]) + rbf(dt * bf_hi(p[e])));
+    *((u32x4*)out + i) = o;
+  }
+  if (i == 0) {  // scalar tail
+    for (long long k = n8 * 8; k < n; ++k) out[k] = f2bf(bf2f(x[k]) + rbf(dt * bf2f(pred[k])));
+  }
+}
+
+// _prepare_latent_images (flux/flux.py:57-58): [B,h,w,C] -> [B,(h/2)(w/2), C*4], feature = c*4+dy*2+dx
+__global__ __launch_bounds__(256) void pack_kernel(const bf16_t* __restrict__ x,
+                                                   bf16_t* __restrict__ out, int B, int h, int w,
+                                                   int C) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)B * h * w * C;
+  if (i >= total) return;
+  int f = (int)(i % (C * 4));
+  long long tok = i / (C * 4);
+  int w2 = w / 2, h2 = h / 2;
+  int tx = (int)(tok % w2);
+  int ty = (int)((tok / w2) % h2);
+  int b = (int)(tok / ((long long)w2 * h2));
+  int c = f >> 2, dy = (f >> 1) & 1, dx = f & 1;
+  out[i] = x[(((long long)b * h + (ty * 2 + dy)) * w + (tx * 2 + dx)) * C + c];
+}
+
+// FluxPipeline.decode unpack (flux/flux.py:159-160) fused with AutoEncoder.decode's affine
+// z / scale_factor + shift_factor (flux/autoencoder.py:353): out[b,y,x,c] NHWC.
+__global__ __launch_bounds__(256) void unpack_kernel(const bf16_t* __restrict__ x,
+                                                     bf16_t* __restrict__ out, int B, int h, int w,
+                                                     int C, float inv_scale, float shift) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)B * h * w * C;
+  if (i >= total) return;
+  int c = (int)(i % C);
+  long long pix = i / C;
+  int xx = (int)(pix % w);
+  int yy = (int)((pix / w) % h);
+  int b = (int)(pix / ((long long)w * h));
+  int w2 = w / 2, h2 = h / 2;
+  long long tok = ((long long)b * h2 + (yy >> 1)) * w2 + (xx >> 1);
+  int f = c * 4 + (yy & 1) * 2 + (xx & 1);
+  out[i] = f2bf(bf2f(x[tok * (C * 4) + f]) * inv_scale + shift);
+}
+
+
+// timestep_embedding (flux/layers.py:46-57) for a bf16 timestep vector: 1000*t is a bf16 product
+// (python scalar x bf16 array), the multiply with the fp32 frequencies promotes to fp32, the
+// [cos | sin] result is cast back to bf16.
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const bf16_t* __restrict__ t,
+                                                                 bf16_t* __restrict__ out, int B,
+                                                                 int dim, float time_factor,
+                                                                 float neg_log_period) {
+  const int half = dim >> 1;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * half) return;
+  int b = i / half, k = i - b * half;
+  float tv = rbf(time_factor * bf2f(t[b]));
+  float f = expf(((float)k / (float)half) * neg_log_period);
+  float a = tv * f;
+  out[(long long)b * dim + k] = f2bf(cosf(a));
+  out[(long long)b * dim + half + k] = f2bf(sinf(a));
+}
+
+// EmbedND / _rope (flux/layers.py:12-21,60-75): per token the (cos, sin) of pos_axis * omega_j for
+// the 64 rotation pairs of a 128-wide head, rounded to bf16 like pe.astype(bf16) (flux/model.py:124).
+__global__ __launch_bounds__(256) void rope_table_kernel(const int* __restrict__ ids,
+                                                         bf16_t* __restrict__ out, long long ntok,
+                                                         int n_axes, int a0, int a1, int a2,
+                                                         float theta) {
+  const int npairs = (a0 + a1 + a2) >> 1;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntok * npairs) return;
+  long long tok = i / npairs;
+  int j = (int)(i - tok * npairs);
+  int axis, jj, dim;
+  if (j < (a0 >> 1)) { axis = 0; jj = j; dim = a0; }
+  else if (j < ((a0 + a1) >> 1)) { axis = 1; jj = j - (a0 >> 1); dim = a1; }
+  else { axis = 2; jj = j - ((a0 + a1) >> 1); dim = a2; }
+  float scale = (float)(2 * jj) / (float)dim;
+  float omega = 1.0f / powf(theta, scale);
+  float x = (float)ids[tok * n_axes + axis] * omega;
+  uint32_t w = pack_bf16x2(cosf(x), sinf(x));
+  *((uint32_t*)out + i) = w;
+}
+
+// Row softmax over float32 logits (single-head VAE attention, flux/autoencoder.py:49), bf16 out.
+// One 256-thread block per row, three passes over L2-resident data.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s,
+                                                           bf16_t* __restrict__ p, int cols, int ld,
+                                                           float scale_log2) {
+  __shared__ float red[8];
+  const long long row = blockIdx.x;
+  const float* sr = s + row * ld;
+  bf16_t* pr = p + row * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nch = cols >> 2;
+  float mx = -1e30f;
+  for (int c = tid; c < nch; c += 256) {
+    f32x4 w = *((const f32x4*)sr + c);
+    mx = fmaxf(mx, fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3])));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float mneg = -mx * scale_log2;
+  float sum = 0.f;
+  for (int c = tid; c < nch; c += 256) {
+    f32x4 w = *((const f32x4*)sr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum += __builtin_amdgcn_exp2f(fmaf(w[e], scale_log2, mneg));
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wv] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = tid; c < nch; c += 256) {
+    f32x4 w = *((const f32x4*)sr + c);
+    u32x2 o;
+    o[0] = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(w[0], scale_log2, mneg)) * inv,
+                       __builtin_amdgcn_exp2f(fmaf(w[1], scale_log2, mneg)) * inv);
+    o[1] = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(w[2], scale_log2, mneg)) * inv,
+                       __builtin_amdgcn_exp2f(fmaf(w[3], scale_log2, mneg)) * inv);
+    *((u32x2*)pr + c) = o;
+  }
+}
+
+// Direct 3x3 conv (pad 1, stride 1) for tiny channel counts: conv_in 16->512 and conv_out 128->3
+// of the Flux decoder (flux/autoencoder.py:224-226,269). One thread per (pixel, output-channel
+// group of COPT); weights [Cout][3][3][Cin]. fp32 accumulate.
+template <int COPT>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+    void* __restrict__ out, int B, int H, int W, int Cin, int Cout, int out_f32, int clip01) {
+  const int cgroups = (Cout + COPT - 1) / COPT;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)B * H * W * cgroups;
+  if (i >= total) return;
+  const int cgp = (int)(i % cgroups);
+  long long pix = i / cgroups;
+  const int xx = (int)(pix % W);
+  const int yy = (int)((pix / W) % H);
+  const int b = (int)(pix / ((long long)W * H));
+  float acc[COPT];
+#pragma unroll
+  for (int o = 0; o < COPT; ++o) {
+    int co = cgp * COPT + o;
+    acc[o] = (bias && co < Cout) ? bf2f(bias[co]) : 0.f;
+  }
+  for (int ky = 0; ky < 3; ++ky) {
+    int y = yy + ky - 1;
+    if (y < 0 || y >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      int xq = xx + kx - 1;
+      if (xq < 0 || xq >= W) continue;
+      const bf16_t* xp = x + (((long long)b * H + y) * W + xq) * Cin;
+      for (int c8 = 0; c8 < Cin; c8 += 8) {
+        u32x4 xv = *(const u32x4*)(xp + c8);
+#pragma unroll
+        for (int o = 0; o < COPT; ++o) {
+          int co = min(cgp * COPT + o, Cout - 1);
+          u32x4 wv = *(const u32x4*)(w + (((long long)co * 3 + ky) * 3 + kx) * Cin + c8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[o] += bf_lo(xv[e]) * bf_lo(wv[e]);
+            acc[o] += bf_hi(xv[e]) * bf_hi(wv[e]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < COPT; ++o) {
+    int co = cgp * COPT + o;
+    if (co >= Cout) continue;
+    float v = acc[o];
+    if (clip01) v = fminf(fmaxf(v + 1.f, 0.f), 2.f) * 0.5f;
+    long long oi = pix * Cout + co;
+    if (out_f32) ((float*)out)[oi] = v;
+    else ((bf16_t*)out)[oi] = f2bf(v);
+  }
+}
+
+}  // namespace
+
+extern "C" int fluxhip_euler_step_bf16(const void* x, const void* pred, void* out, int64_t n,
+                                       float dt, void* stream) {
+  if (!x || !pred || !out || n < 1) return FLUXHIP_EINVAL;
+  long long n8 = n / 8;
+  unsigned blocks = (unsigned)((n8 + 255) / 256);
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(euler_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)pred, (bf16_t*)out, n8, (long long)n, dt);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_pack_latents_bf16(const void* x, void* out, int B, int h, int w, int C,
+                                         void* stream) {
+  if (!x || !out || B < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || C < 1) return FLUXHIP_EINVAL;
+  long long total = (long long)B * h * w * C;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, B, h, w, C);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_unpack_latents_bf16(const void* x, void* out, int B, int h, int w, int C,
+                                           float scale, float shift, void* stream) {
+  if (!x || !out || B < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || C < 1 || scale == 0.f)
+    return FLUXHIP_EINVAL;
+  long long total = (long long)B * h * w * C;
+  hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, B, h, w, C, 1.f / scale,
+                     shift);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_softmax_rows_f32(const void* s, void* p, int64_t rows, int cols, int ld,
+                                        float scale, void* stream) {
+  if (!s || !p || rows < 1 || cols < 4 || cols % 4 || ld % 4 || ld < cols) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)s, (bf16_t*)p, cols, ld, scale * 1.4426950408889634f);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_conv2d_small(const void* x, const void* w, const void* bias, void* out,
+                                    int B, int H, int W, int Cin, int Cout, int out_f32, int clip01,
+                                    void* stream) {
+  if (!x || !w || !out || B < 1 || H < 1 || W < 1 || Cin % 8 || Cout < 1) return FLUXHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout <= 4) {
+    long long total = (long long)B * H * W;
+    hipLaunchKernelGGL((conv3x3_small_kernel<4>), dim3((unsigned)((total + 255) / 256)), dim3(256),
+                       0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)bias, out, B, H, W,
+                       Cin, Cout, out_f32, clip01);
+  } else {
+    long long total = (long long)B * H * W * ((Cout + 7) / 8);
+    hipLaunchKernelGGL((conv3x3_small_kernel<8>), dim3((unsigned)((total + 255) / 256)), dim3(256),
+                       0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)bias, out, B, H, W,
+                       Cin, Cout, out_f32, clip01);
+  }
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_timestep_embedding_bf16(const void* t, void* out, int B, int dim,
+                                               float time_factor, float max_period, void* stream) {
+  if (!t || !out || B < 1 || dim < 2 || (dim & 1)) return FLUXHIP_EINVAL;
+  int n = B * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)t, (bf16_t*)out, B, dim, time_factor,
+                     -logf(max_period));
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_rope_table_bf16(const void* ids, void* out, int64_t ntok, int n_axes, int a0,
+                                       int a1, int a2, float theta, void* stream) {
+  if (!ids || !out || ntok < 1 || n_axes != 3 || (a0 & 1) || (a1 & 1) || (a2 & 1))
+    return FLUXHIP_EINVAL;
+  long long n = ntok * ((a0 + a1 + a2) / 2);
+  hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const int*)ids, (bf16_t*)out, (long long)ntok, n_axes,
+                     a0, a1, a2, theta);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}

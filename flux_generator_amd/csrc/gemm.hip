@@ -1,0 +1,165 @@
+// Host launchers for the bf16 NT GEMM / implicit-GEMM conv (kernel: gemm_core.h).
+#include "../../include/fluxhip.h"
+#include "gemm_core.h"
+
+namespace {
+
+struct TileCfg {
+  int bm, bn, threads, lds;
+  void (*dense)(const GemmParams);
+  void (*conv)(const GemmParams);
+};
+
+template <int BM, int BN, int WM, int WN>
+constexpr TileCfg make_cfg() {
+  return TileCfg{BM, BN, WM * WN * 64, 2 * (BM + BN) * 64 * 2,
+                 gemm_nt_kernel<BM, BN, WM, WN, 0>, gemm_nt_kernel<BM, BN, WM, WN, 1>};
+}
+
+// index 0 is unused ("auto")
+const TileCfg kCfgs[] = {
+    TileCfg{0, 0, 0, 0, nullptr, nullptr},
+    make_cfg<128, 128, 2, 2>(),  // 1: default large tile, 64 KiB LDS, 2 blocks/CU
+    make_cfg<128, 64, 2, 2>(),   // 2: more blocks for N=3072 outputs at small M
+    make_cfg<64, 128, 2, 2>(),   // 3
+    make_cfg<64, 64, 2, 2>(),    // 4: tiny problems (N=64 final layer)
+    make_cfg<256, 128, 4, 2>(),  // 5: 8 waves, fewer LDS bytes per flop
+    make_cfg<128, 256, 2, 4>(),  // 6
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+bool g_attr_set[kNumCfgs][2] = {};
+
+int pick_cfg(long long m_total, int N) {
+  // enough 128x128 tiles to give every CU >= 2 blocks -> big tile; otherwise shrink N-tile.
+  long long t128 = ((m_total + 127) / 128) * ((N + 127) / 128);
+  if (N <= 64) return 4;
+  if (t128 >= 512) return 1;
+  long long t12864 = ((m_total + 127) / 128) * ((N + 63) / 64);
+  if (t12864 >= 384) return 2;
+  return 4;
+}
+
+int launch(GemmParams& p, int cfg_idx, bool conv, hipStream_t s) {
+  if (cfg_idx <= 0 || cfg_idx >= kNumCfgs) return FLUXHIP_EINVAL;
+  const TileCfg& c = kCfgs[cfg_idx];
+  int tm_total = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    p.g[g].tiles_m = (p.g[g].M + c.bm - 1) / c.bm;
+    tm_total += p.g[g].tiles_m * p.nbatch;
+  }
+  if (p.ngroups == 1) p.g[1] = p.g[0];
+  p.tiles_m_total = tm_total;
+  p.tiles_n = (p.N + c.bn - 1) / c.bn;
+  auto fn = conv ? c.conv : c.dense;
+  if (!g_attr_set[cfg_idx][conv]) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) !=
+        hipSuccess)
+      return FLUXHIP_ELAUNCH;
+    g_attr_set[cfg_idx][conv] = true;
+  }
+  dim3 grid(tm_total * p.tiles_n), block(c.threads);
+  hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
+  if (!d || d->ngroups < 1 || d->ngroups > 2 || d->nbatch < 1) return FLUXHIP_EINVAL;
+  if (d->K <= 0 || d->K % 64 || d->N <= 0 || d->N % 4 || d->lda % 8 || d->ldc % 4)
+    return FLUXHIP_EINVAL;
+  GemmParams p{};
+  long long m_total = 0;
+  for (int g = 0; g < d->ngroups; ++g) {
+    const fluxhip_gemm_group& s = d->g[g];
+    if (!s.A || !s.W || !s.C || s.M <= 0) return FLUXHIP_EINVAL;
+    if (d->epi == FLUXHIP_EPI_GATE_RES && !s.res) return FLUXHIP_EINVAL;
+    GemmGroup& t = p.g[g];
+    t.A = (const bf16_t*)s.A;
+    t.W = (const bf16_t*)s.W;
+    t.bias = (const bf16_t*)s.bias;
+    t.C = (bf16_t*)s.C;
+    t.res = (const bf16_t*)s.res;
+    t.gate = (const bf16_t*)s.gate;
+    t.a_bstride = s.a_bstride;
+    t.c_bstride = s.c_bstride;
+    t.gate_bstride = s.gate_bstride;
+    t.M = s.M;
+    m_total += (long long)s.M * d->nbatch;
+  }
+  if (d->epi == FLUXHIP_EPI_SPLIT_GELU && (!d->C2 || d->n_split % 4 || d->ldc2 % 4 || d->c2_coloff % 4))
+    return FLUXHIP_EINVAL;
+  p.ngroups = d->ngroups;
+  p.nbatch = d->nbatch;
+  p.N = d->N;
+  p.K = d->K;
+  p.lda = d->lda;
+  p.ldc = d->ldc;
+  p.epi = d->epi;
+  p.row_bias = d->row_bias;
+  p.n_split = d->n_split;
+  p.C2 = (bf16_t*)d->C2;
+  p.ldc2 = d->ldc2;
+  p.c2_bstride = d->c2_bstride;
+  p.c2_coloff = d->c2_coloff;
+  p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+  p.out_f32 = d->out_f32;
+  if (p.out_f32 && d->epi != FLUXHIP_EPI_BIAS) return FLUXHIP_EINVAL;
+  int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(m_total, d->N);
+  return launch(p, cfg, false, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d) {
+  if (!d || d->ngroups < 1 || d->ngroups > 2) return FLUXHIP_EINVAL;
+  if (d->tile_cfg > 0) return d->tile_cfg < kNumCfgs ? d->tile_cfg : FLUXHIP_EINVAL;
+  long long m_total = 0;
+  for (int g = 0; g < d->ngroups; ++g) m_total += (long long)d->g[g].M * d->nbatch;
+  return pick_cfg(m_total, d->N);
+}
+
+extern "C" int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads) {
+  if (cfg <= 0 || cfg >= kNumCfgs || !bm || !bn || !threads) return FLUXHIP_EINVAL;
+  *bm = kCfgs[cfg].bm;
+  *bn = kCfgs[cfg].bn;
+  *threads = kCfgs[cfg].threads;
+  return FLUXHIP_OK;
+}
+
+extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bias, const void* res,
+                                   void* out, int B, int Hs, int Ws, int Cin, int Cout, int ksize,
+                                   int stride, int pad, int ups, int epi, const void* zero16,
+                                   void* stream) {
+  if (!x || !w || !out || !zero16) return FLUXHIP_EINVAL;
+  if (Cin % 64 || Cout % 4 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
+    return FLUXHIP_EINVAL;
+  if (epi != FLUXHIP_EPI_BIAS && epi != FLUXHIP_EPI_GATE_RES && epi != FLUXHIP_EPI_SILU)
+    return FLUXHIP_EINVAL;
+  if (epi == FLUXHIP_EPI_GATE_RES && !res) return FLUXHIP_EINVAL;
+  const int Hl = ups ? Hs * 2 : Hs, Wl = ups ? Ws * 2 : Ws;
+  const int Ho = (Hl + 2 * pad - ksize) / stride + 1;
+  const int Wo = (Wl + 2 * pad - ksize) / stride + 1;
+  GemmParams p{};
+  p.cv.X = (const bf16_t*)x;
+  p.cv.zero = (const bf16_t*)zero16;
+  p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Ho; p.cv.Wo = Wo;
+  p.cv.Cin = Cin; p.cv.ksize = ksize; p.cv.stride = stride; p.cv.pad = pad; p.cv.ups = ups;
+  GemmGroup& t = p.g[0];
+  t.A = (const bf16_t*)x;
+  t.W = (const bf16_t*)w;
+  t.bias = (const bf16_t*)bias;
+  t.C = (bf16_t*)out;
+  t.res = (const bf16_t*)res;
+  t.gate = nullptr;
+  t.M = B * Ho * Wo;
+  p.ngroups = 1;
+  p.nbatch = 1;
+  p.N = Cout;
+  p.K = ksize * ksize * Cin;
+  p.lda = Cin;
+  p.ldc = Cout;
+  p.epi = epi;
+  p.alpha = 1.f;
+  int cfg = pick_cfg(t.M, Cout);
+  return launch(p, cfg, true, (hipStream_t)stream);
+}

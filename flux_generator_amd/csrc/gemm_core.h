@@ -1,0 +1,305 @@
+// bf16 "NT" GEMM main loop for gfx950:  C[M,N] = A[M,K] * W[N,K]^T (+ fused epilogue)
+//
+// This is the contraction behind every Linear on the Flux denoise path
+// (reference: flux/layers.py:104-106,163-165,250-252 and flux/model.py:56,64) and,
+// with the implicit-GEMM A loader, behind the VAE / UNet 3x3 convolutions
+// (reference: flux/autoencoder.py:70-81,117-122).
+//
+// Design (MI355X-first, not a translation of anything):
+//  * 64-lane waves, v_mfma_f32_16x16x32_bf16, fp32 accumulators.
+//  * Both operands are K-contiguous, so A and W tiles are staged with
+//    global_load_lds_dwordx4 (16 B / lane, 1 KiB / wave-instruction) straight
+//    into LDS, double-buffered, one barrier per K-step of 64.
+//  * LDS image is lane-linear (hardware constraint of the LDS-DMA), so the bank
+//    swizzle lives on the *source* address: 16-B chunk c of tile row r is fetched
+//    into physical chunk c ^ (r & 7); fragment reads apply the same XOR. With
+//    128-B rows this makes every ds_read_b128 lane group hit 16 distinct slots.
+//  * MFMA operands are swapped (W fragment as "A", activation fragment as "B") so
+//    that each lane ends up holding 4 *consecutive output columns* of one row:
+//    epilogue loads/stores are 8-byte vectors, bias/gate are read as 4 bf16.
+//  * Workgroup -> tile mapping is XCD-aware: the 8 XCDs (private L2 each) get
+//    contiguous ranges of N-tiles with all M-tiles of that range, so every weight
+//    panel is pulled from HBM by exactly one XCD.
+#pragma once
+#include "common.h"
+
+enum GemmEpi : int {
+  EPI_BIAS = 0,       // C = acc + bias
+  EPI_GELU_TANH = 1,  // C = gelu_tanh(acc + bias)
+  EPI_GATE_RES = 2,   // C = res + gate[b,n] * (acc + bias)      (gate may be null -> 1)
+  EPI_SPLIT_GELU = 3, // n <  n_split: C  = acc + bias
+                      // n >= n_split: C2[:, n - n_split + c2_coloff] = gelu_tanh(acc + bias)
+  EPI_SILU = 4,       // C = silu(acc + bias)
+  EPI_GEGLU = 5,      // reserved (UNet)
+};
+
+struct GemmGroup {
+  const bf16_t* A;     // [nbatch][M][lda]   (dense A loader)
+  const bf16_t* W;     // [N][K]
+  const bf16_t* bias;  // [N] or null  (row_bias: [M])
+  bf16_t* C;           // [nbatch][M][ldc]
+  const bf16_t* res;   // residual, same indexing as C (EPI_GATE_RES)
+  const bf16_t* gate;  // [nbatch][gate_bstride] or null
+  long long a_bstride; // elements between batches of A
+  long long c_bstride; // elements between batches of C / res
+  long long gate_bstride;
+  int M;               // rows per batch
+  int tiles_m;         // ceil(M / BM)
+};
+
+struct ConvGeom {        // implicit-GEMM A loader (NHWC activations)
+  const bf16_t* X;       // [B][Hs][Ws][Cin]
+  const bf16_t* zero;    // >= 16 zero bytes (border taps read this)
+  int Hs, Ws;            // stored (source) resolution
+  int Ho, Wo;            // output resolution
+  int Cin;               // multiple of 64
+  int ksize;             // 1 or 3
+  int stride;            // 1 or 2
+  int pad;               // 0 or 1
+  int ups;               // 1: input is nearest-upsampled x2 on the fly
+};
+
+struct GemmParams {
+  GemmGroup g[2];
+  ConvGeom cv;
+  int ngroups, nbatch;
+  int N, K;
+  int lda, ldc;
+  int epi;
+  int row_bias;          // bias indexed by output row instead of column
+  int n_split;
+  bf16_t* C2;
+  int ldc2;
+  long long c2_bstride;
+  int c2_coloff;
+  int tiles_m_total, tiles_n;
+  float alpha;           // scales acc before bias (attention logits etc.)
+  int out_f32;           // EPI_BIAS only: C is float32 (logits of the single-head VAE attention)
+};
+
+template <int BM, int BN, int WM, int WN, int AMODE>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p) {
+  constexpr int BK = 64;
+  constexpr int NWAVES = WM * WN;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 16, NJ = WTN / 16;
+  constexpr int APW = BM / 8 / NWAVES, BPW = BN / 8 / NWAVES;
+  static_assert(APW >= 1 && BPW >= 1, "tile too small for wave count");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- XCD-aware, bijective block -> tile map -------------------------------
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int TM = p.tiles_m_total;
+  int tm = swz % TM;
+  const int tn = swz / TM;
+
+  const int tm0 = p.nbatch * p.g[0].tiles_m;
+  const bool g1 = tm >= tm0;
+  if (g1) tm -= tm0;
+  const bf16_t* gA = g1 ? p.g[1].A : p.g[0].A;
+  const bf16_t* gW = g1 ? p.g[1].W : p.g[0].W;
+  const bf16_t* gBias = g1 ? p.g[1].bias : p.g[0].bias;
+  bf16_t* gC = g1 ? p.g[1].C : p.g[0].C;
+  const bf16_t* gRes = g1 ? p.g[1].res : p.g[0].res;
+  const bf16_t* gGate = g1 ? p.g[1].gate : p.g[0].gate;
+  const long long a_bs = g1 ? p.g[1].a_bstride : p.g[0].a_bstride;
+  const long long c_bs = g1 ? p.g[1].c_bstride : p.g[0].c_bstride;
+  const long long gate_bs = g1 ? p.g[1].gate_bstride : p.g[0].gate_bstride;
+  const int Mg = g1 ? p.g[1].M : p.g[0].M;
+  const int tpb = g1 ? p.g[1].tiles_m : p.g[0].tiles_m;
+  const int b = tm / tpb;
+  const int m0 = (tm % tpb) * BM;
+  const int n0 = tn * BN;
+  const int N = p.N, K = p.K;
+
+  // ---- per-lane staging sources ----------------------------------------------
+  const int lr = lane >> 3;             // row inside an 8-row piece
+  const int lc = (lane & 7) ^ lr;       // logical 16-B chunk fetched by this lane
+  const char* asrc[APW];
+  int arow[APW];                        // conv: packed output-pixel coords
+  const char* bsrc[BPW];
+#pragma unroll
+  for (int i = 0; i < APW; ++i) {
+    int row = (wave + i * NWAVES) * 8 + lr;
+    int grow = min(m0 + row, Mg - 1);
+    if (AMODE == 0) {
+      asrc[i] = (const char*)(gA + (long long)b * a_bs + (long long)grow * p.lda) + lc * 16;
+      arow[i] = 0;
+    } else {
+      asrc[i] = nullptr;
+      arow[i] = grow;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BPW; ++i) {
+    int row = (wave + i * NWAVES) * 8 + lr;
+    int n = min(n0 + row, N - 1);
+    bsrc[i] = (const char*)(gW + (long long)n * K) + lc * 16;
+  }
+
+  // conv geometry decode (per staged row), hoisted out of the K loop
+  int cy[APW], cx[APW];
+  const char* cbase[APW];
+  if (AMODE == 1) {
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+      int pix = arow[i];
+      int hw = p.cv.Ho * p.cv.Wo;
+      int bb = pix / hw;
+      int rem = pix - bb * hw;
+      int y = rem / p.cv.Wo;
+      int x = rem - y * p.cv.Wo;
+      cy[i] = y * p.cv.stride - p.cv.pad;
+      cx[i] = x * p.cv.stride - p.cv.pad;
+      cbase[i] = (const char*)(p.cv.X + (long long)bb * p.cv.Hs * p.cv.Ws * p.cv.Cin) + lc * 16;
+    }
+  }
+
+  auto stage = [&](int kt, int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    char* sb = sa + A_BYTES;
+    if (AMODE == 0) {
+#pragma unroll
+      for (int i = 0; i < APW; ++i)
+        glds16(asrc[i] + (long long)kt * (BK * 2), sa + (wave + i * NWAVES) * 1024);
+    } else {
+      const int kpc = p.cv.Cin >> 6;          // K-steps per filter tap
+      const int tap = kt / kpc;
+      const int c0 = (kt - tap * kpc) << 6;
+      const int dy = (p.cv.ksize == 3) ? tap / 3 : 0;
+      const int dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
+      const int Hl = p.cv.ups ? p.cv.Hs * 2 : p.cv.Hs;   // logical input grid
+      const int Wl = p.cv.ups ? p.cv.Ws * 2 : p.cv.Ws;
+#pragma unroll
+      for (int i = 0; i < APW; ++i) {
+        int yy = cy[i] + dy, xx = cx[i] + dx;
+        bool ok = (yy >= 0) & (yy < Hl) & (xx >= 0) & (xx < Wl);
+        int ys = p.cv.ups ? (yy >> 1) : yy;
+        int xs = p.cv.ups ? (xx >> 1) : xx;
+        const char* src = ok ? cbase[i] + ((long long)(ys * p.cv.Ws + xs) * p.cv.Cin + c0) * 2
+                             : (const char*)p.cv.zero;
+        glds16(src, sa + (wave + i * NWAVES) * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BPW; ++i)
+      glds16(bsrc[i] + (long long)kt * (BK * 2), sb + (wave + i * NWAVES) * 1024);
+  };
+
+  // ---- fragment read offsets (same XOR as the staging source swizzle) ---------
+  const int r16 = lane & 15, q4 = lane >> 4;
+  int foff[2];
+  foff[0] = r16 * 128 + (((0 + q4) ^ (lane & 7)) << 4);
+  foff[1] = r16 * 128 + (((4 + q4) ^ (lane & 7)) << 4);
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / BK;
+  stage(0, 0);
+  wait_vm0();
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+    const char* sa = smem + cur * STAGE_BYTES + (wm * WTM) * 128;
+    const char* sb = smem + cur * STAGE_BYTES + A_BYTES + (wn * WTN) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[MI], wf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 2048 + foff[kk]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(sb + j * 2048 + foff[kk]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    wait_vm0();
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m][n4 .. n4+3] -----------------------------------
+  const int epi = p.epi;
+  const float alpha = p.alpha;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + r16;
+    if (m >= Mg) continue;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
+      if (n4 >= N) continue;
+      float v[4];
+      if (gBias) {
+        if (p.row_bias) {
+          float bv = bf2f(gBias[m]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha + bv;
+        } else {
+          u32x2 bw = *(const u32x2*)(gBias + n4);
+          v[0] = acc[i][j][0] * alpha + bf_lo(bw[0]);
+          v[1] = acc[i][j][1] * alpha + bf_hi(bw[0]);
+          v[2] = acc[i][j][2] * alpha + bf_lo(bw[1]);
+          v[3] = acc[i][j][3] * alpha + bf_hi(bw[1]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
+      }
+      if (p.out_f32) {
+        float* fdst = (float*)gC + (long long)b * c_bs + (long long)m * p.ldc + n4;
+        *(f32x4*)fdst = f32x4{v[0], v[1], v[2], v[3]};
+        continue;
+      }
+      bf16_t* dst = gC + (long long)b * c_bs + (long long)m * p.ldc + n4;
+      if (epi == EPI_GELU_TANH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(rbf(v[r]));
+      } else if (epi == EPI_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(rbf(v[r]));
+      } else if (epi == EPI_GATE_RES) {
+        const bf16_t* rp = gRes + (long long)b * c_bs + (long long)m * p.ldc + n4;
+        u32x2 rw = *(const u32x2*)rp;
+        float rr[4] = {bf_lo(rw[0]), bf_hi(rw[0]), bf_lo(rw[1]), bf_hi(rw[1])};
+        if (gGate) {
+          u32x2 gw = *(const u32x2*)(gGate + (long long)b * gate_bs + n4);
+          float gg[4] = {bf_lo(gw[0]), bf_hi(gw[0]), bf_lo(gw[1]), bf_hi(gw[1])};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rr[r] + rbf(gg[r] * rbf(v[r]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rr[r] + rbf(v[r]);
+        }
+      } else if (epi == EPI_SPLIT_GELU) {
+        if (n4 >= p.n_split) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(rbf(v[r]));
+          dst = p.C2 + (long long)b * p.c2_bstride + (long long)m * p.ldc2 +
+                (n4 - p.n_split + p.c2_coloff);
+        }
+      }
+      u32x2 o;
+      o[0] = pack_bf16x2(v[0], v[1]);
+      o[1] = pack_bf16x2(v[2], v[3]);
+      *(u32x2*)dst = o;
+    }
+  }
+}

@@ -1,0 +1,171 @@
+"""FluxPipeline — the reference's generator surface (flux/flux.py:22-193) over the HIP hot path.
+
+Kept verbatim: ``FluxPipeline(name, t5_padding=True)``, ``generate_latents`` (a generator whose first
+yield is the conditioning tuple and whose next ``num_steps`` yields are x_t), ``decode``,
+``generate_images``, ``tokenize``, ``ensure_models_are_loaded``, ``reload_text_encoders``.
+Added for the north-star wording: ``FluxPipeline(model="schnell")`` alias and ``.generate()``.
+Training / LoRA methods are out of the hot-path scope.
+
+Execution: each denoise step = one launch plan of libfluxhip kernels (flux/model.py) + one Euler
+kernel.  With ``use_graph=True`` (default) the plan of a given (B, S, L) shape is captured once into
+a hipGraph and replayed per step, which removes ~350 host launches per step from the critical path.
+Eager torch has no lazy evaluation: every ``next()`` returns an enqueued step; the caller
+synchronises when it reads (the analogue of the reference's ``mx.eval``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .. import ops
+from .sampler import FluxSampler
+from .utils import load_ae, load_clip, load_clip_tokenizer, load_flow_model, load_t5, load_t5_tokenizer
+
+try:
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(x, **kw):
+        return x
+
+
+class FluxPipeline:
+    def __init__(self, name: Optional[str] = None, t5_padding: bool = True, model: Optional[str] = None,
+                 device: str = "cuda", use_graph: bool = True):
+        name = name if name is not None else model
+        if name is None:
+            raise ValueError("FluxPipeline needs a model name ('flux-schnell' or 'flux-dev')")
+        if not name.startswith("flux-"):
+            name = "flux-" + name
+        self.dtype = torch.bfloat16
+        self.name = name
+        self.t5_padding = t5_padding
+        self.device = torch.device(device)
+        self.use_graph = use_graph
+
+        self.ae = load_ae(name, device=device)
+        self.flow = load_flow_model(name, device=device)
+        self.clip = load_clip(name, device=device)
+        self.clip_tokenizer = load_clip_tokenizer(name)
+        self.t5 = load_t5(name, device=device)
+        self.t5_tokenizer = load_t5_tokenizer(name)
+        self.sampler = FluxSampler(name)
+        self._graphs = {}
+
+    def ensure_models_are_loaded(self):
+        torch.cuda.synchronize(self.device)
+
+    def reload_text_encoders(self):
+        self.t5 = load_t5(self.name, device=self.device)
+        self.clip = load_clip(self.name, device=self.device)
+
+    def tokenize(self, text):
+        t5_tokens = self.t5_tokenizer.encode(text, pad=self.t5_padding)
+        clip_tokens = self.clip_tokenizer.encode(text)
+        return t5_tokens, clip_tokens
+
+    def _prepare_latent_images(self, x: torch.Tensor):
+        """flux/flux.py:53-71: 2x2 pack (HIP kernel) + (0,row,col) position ids."""
+        b, h, w, c = x.shape
+        packed = ops.pack_latents(x.contiguous())
+        j, k = torch.meshgrid(torch.arange(h // 2, dtype=torch.int32, device=x.device),
+                              torch.arange(w // 2, dtype=torch.int32, device=x.device), indexing="ij")
+        x_ids = torch.stack([torch.zeros_like(j), j, k], dim=-1).reshape(1, h * w // 4, 3).repeat(b, 1, 1)
+        return packed, x_ids.contiguous()
+
+    def _prepare_conditioning(self, n_images, t5_tokens, clip_tokens):
+        """flux/flux.py:73-85."""
+        txt = self.t5(t5_tokens)
+        if len(txt) == 1 and n_images > 1:
+            txt = txt.expand(n_images, *txt.shape[1:]).contiguous()
+        txt_ids = torch.zeros((n_images, txt.shape[1], 3), dtype=torch.int32, device=txt.device)
+        vec = self.clip(clip_tokens).pooled_output
+        if len(vec) == 1 and n_images > 1:
+            vec = vec.expand(n_images, *vec.shape[1:]).contiguous()
+        return txt, txt_ids, vec
+
+    # ------------------------------------------------------------------ denoise step execution
+    def _flow_step(self, x_t, x_ids, txt, txt_ids, vec, t_vec, guidance) -> torch.Tensor:
+        """pred = flow(...) — eagerly, or by replaying the captured hipGraph of this shape."""
+        if not self.use_graph:
+            return self.flow(img=x_t, img_ids=x_ids, txt=txt, txt_ids=txt_ids, y=vec, timesteps=t_vec, guidance=guidance)
+        B, L, _ = x_t.shape
+        S = txt.shape[1]
+        ws = self.flow._workspace(B, S, L)
+        ws["in_img"].copy_(x_t)
+        ws["in_txt"].copy_(txt)
+        ws["in_y"].copy_(vec)
+        ws["in_t"].copy_(t_vec)
+        ws["in_g"].copy_(guidance)
+        if S > 0:
+            ws["in_ids"][:, :S].copy_(txt_ids)
+        ws["in_ids"][:, S:].copy_(x_ids)
+        g = self._graphs.get((B, S, L))
+        if g is None:
+            # warm up once on a side stream (first-touch attribute calls), then capture
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.flow.run_plan(ws)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.flow.run_plan(ws)
+            self._graphs[(B, S, L)] = g
+        g.replay()
+        return ws["pred"]
+
+    def _denoising_loop(self, x_t, x_ids, txt, txt_ids, vec, num_steps: int = 35, guidance: float = 4.0,
+                        start: float = 1, stop: float = 0):
+        """flux/flux.py:87-126."""
+        B = len(x_t)
+
+        def scalar(x):
+            return torch.full((B,), x, dtype=self.dtype, device=x_t.device)
+
+        guidance = scalar(guidance)
+        timesteps = self.sampler.timesteps(num_steps, x_t.shape[1], start=start, stop=stop)
+        for i in range(num_steps):
+            t, t_prev = timesteps[i], timesteps[i + 1]
+            pred = self._flow_step(x_t, x_ids, txt, txt_ids, vec, scalar(t), guidance)
+            x_t = self.sampler.step(pred, x_t, t, t_prev)
+            yield x_t
+
+    def generate_latents(self, text: str, n_images: int = 1, num_steps: int = 35, guidance: float = 4.0,
+                         latent_size: Tuple[int, int] = (64, 64), seed=None):
+        """flux/flux.py:128-155."""
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=self.device).manual_seed(seed)
+        x_T = self.sampler.sample_prior((n_images, *latent_size, 16), dtype=self.dtype, key=gen, device=self.device)
+        x_T, x_ids = self._prepare_latent_images(x_T)
+        t5_tokens, clip_tokens = self.tokenize(text)
+        txt, txt_ids, vec = self._prepare_conditioning(n_images, t5_tokens, clip_tokens)
+        yield (x_T, x_ids, txt, txt_ids, vec)
+        yield from self._denoising_loop(x_T, x_ids, txt, txt_ids, vec, num_steps=num_steps, guidance=guidance)
+
+    def decode(self, x: torch.Tensor, latent_size: Tuple[int, int] = (64, 64)) -> torch.Tensor:
+        """flux/flux.py:157-162: [b,L,64] -> [b,8h,8w,3] float in [0,1] (unpack, VAE decode, clip fused)."""
+        return self.ae.decode_packed(x, latent_size)
+
+    def generate_images(self, text: str, n_images: int = 1, num_steps: int = 35, guidance: float = 4.0,
+                        latent_size: Tuple[int, int] = (64, 64), seed=None, reload_text_encoders: bool = True,
+                        progress: bool = True):
+        """flux/flux.py:164-193."""
+        latents = self.generate_latents(text, n_images, num_steps, guidance, latent_size, seed)
+        next(latents)
+        if reload_text_encoders:
+            self.reload_text_encoders()
+        x_t = None
+        for x_t in tqdm(latents, total=num_steps, disable=not progress, leave=True):
+            pass
+        images = []
+        for i in tqdm(range(len(x_t)), disable=not progress, desc="generate images"):
+            images.append(self.decode(x_t[i:i + 1], latent_size))
+        images = torch.cat(images, dim=0)
+        torch.cuda.synchronize(self.device)
+        return images
+
+    def generate(self, *args, **kwargs):
+        """Alias of generate_images (BASELINE.json north_star wording)."""
+        return self.generate_images(*args, **kwargs)

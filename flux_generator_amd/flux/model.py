@@ -1,0 +1,381 @@
+"""Flux MMDiT on MI355X: host-side mirror of the reference's ``flux/model.py``.
+
+Same constructor argument (FluxParams), same ``__call__(img, img_ids, txt, txt_ids, timesteps, y,
+guidance)`` contract and ValueErrors as the reference (flux/model.py:35-136); the body is a fixed
+*launch plan* of libfluxhip kernels over a preallocated HBM workspace:
+
+  * activations live in ONE packed token buffer x[B, T = S + L, D] with the txt rows first
+    (the reference concatenates txt/img for attention in every double block and again before the
+    single blocks, flux/layers.py:212-214, flux/model.py:129 — here nothing is ever concatenated);
+  * the txt and img streams of a DoubleStreamBlock run as 2-group GEMM launches;
+  * all 2*19 + 38 + 1 modulation Linears depend only on ``vec``: their weights are stored
+    row-concatenated and evaluated by one HBM-bound launch per step;
+  * q/k RMSNorm + RoPE + the V transpose are one launch, attention one launch; gated residuals,
+    GELU and the single-block [attn | gelu(mlp)] concat are GEMM epilogues.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Tuple, Union
+
+import torch
+
+from .. import _lib
+from .. import ops
+from ..ops import EPI_BIAS, EPI_GATE_RES, EPI_GELU_TANH, EPI_SPLIT_GELU, FluxHipError, make_gemm_desc
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class FluxParams:
+    """flux/model.py:20-32."""
+    in_channels: int
+    vec_in_dim: int
+    context_in_dim: int
+    hidden_size: int
+    mlp_ratio: float
+    num_heads: int
+    depth: int
+    depth_single_blocks: int
+    axes_dim: List[int]
+    theta: int
+    qkv_bias: bool
+    guidance_embed: bool
+
+
+class Flux:
+    def __init__(self, params: FluxParams, device: Union[str, torch.device] = "cuda"):
+        # same argument checks as flux/model.py:42-50
+        if params.hidden_size % params.num_heads != 0:
+            raise ValueError(f"Hidden size {params.hidden_size} must be divisible by num_heads {params.num_heads}")
+        pe_dim = params.hidden_size // params.num_heads
+        if sum(params.axes_dim) != pe_dim:
+            raise ValueError(f"Got {params.axes_dim} but expected positional dim {pe_dim}")
+        if pe_dim != 128 or len(params.axes_dim) != 3:
+            raise ValueError("libfluxhip attention is built for head_dim 128 and 3 position axes")
+        self.params = params
+        self.in_channels = params.in_channels
+        self.out_channels = params.in_channels
+        self.hidden_size = params.hidden_size
+        self.num_heads = params.num_heads
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise FluxHipError("Flux needs a HIP device: there is no CPU fallback for the denoise path")
+        _lib.load()
+        self._alloc_parameters()
+        self._ws: Dict[Tuple[int, int, int], dict] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def _alloc_parameters(self) -> None:
+        P, D = self.params, self.params.hidden_size
+        mlp = int(D * P.mlp_ratio)
+        dev = self.device
+        W: Dict[str, torch.Tensor] = {}
+
+        # row-concatenated modulation table: [img_mod, txt_mod] x depth, modulation x singles, final adaLN
+        rows, off = 0, {}
+        for i in range(P.depth):
+            for st in ("img", "txt"):
+                off[f"double_blocks.{i}.{st}_mod.lin"] = rows
+                rows += 6 * D
+        for i in range(P.depth_single_blocks):
+            off[f"single_blocks.{i}.modulation.lin"] = rows
+            rows += 3 * D
+        off["final_layer.adaLN_modulation.layers.1"] = rows
+        rows += 2 * D
+        self.mod_rows, self.mod_off = rows, off
+        self.mod_w = torch.empty(rows, D, dtype=BF16, device=dev)
+        self.mod_b = torch.empty(rows, dtype=BF16, device=dev)
+        sizes = {k: (6 * D if "double" in k else 3 * D if "single" in k else 2 * D) for k in off}
+        for k, o in off.items():
+            W[f"{k}.weight"] = self.mod_w[o:o + sizes[k]]
+            W[f"{k}.bias"] = self.mod_b[o:o + sizes[k]]
+
+        def lin(name, out_d, in_d, bias=True):
+            W[f"{name}.weight"] = torch.empty(out_d, in_d, dtype=BF16, device=dev)
+            if bias:
+                W[f"{name}.bias"] = torch.empty(out_d, dtype=BF16, device=dev)
+
+        lin("img_in", D, P.in_channels)
+        lin("txt_in", D, P.context_in_dim)
+        emb = [("time_in", 256), ("vector_in", P.vec_in_dim)] + ([("guidance_in", 256)] if P.guidance_embed else [])
+        for e, d in emb:
+            lin(f"{e}.in_layer", D, d)
+            lin(f"{e}.out_layer", D, D)
+        hd = D // P.num_heads
+        for i in range(P.depth):
+            p = f"double_blocks.{i}"
+            for st in ("img", "txt"):
+                lin(f"{p}.{st}_attn.qkv", 3 * D, D, bias=P.qkv_bias)
+                W[f"{p}.{st}_attn.norm.query_norm.weight"] = torch.empty(hd, dtype=BF16, device=dev)
+                W[f"{p}.{st}_attn.norm.key_norm.weight"] = torch.empty(hd, dtype=BF16, device=dev)
+                lin(f"{p}.{st}_attn.proj", D, D)
+                lin(f"{p}.{st}_mlp.layers.0", mlp, D)
+                lin(f"{p}.{st}_mlp.layers.2", D, mlp)
+        for i in range(P.depth_single_blocks):
+            p = f"single_blocks.{i}"
+            lin(f"{p}.linear1", 3 * D + mlp, D)
+            lin(f"{p}.linear2", D, D + mlp)
+            W[f"{p}.norm.query_norm.weight"] = torch.empty(hd, dtype=BF16, device=dev)
+            W[f"{p}.norm.key_norm.weight"] = torch.empty(hd, dtype=BF16, device=dev)
+        lin("final_layer.linear", P.in_channels, D)
+        self._params = W
+
+    def parameters(self) -> Dict[str, torch.Tensor]:
+        return self._params
+
+    def init_random(self, seed: int = 0) -> "Flux":
+        """Random init with the reference framework's defaults:
+        U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for Linear weight and bias, 1 for RMSNorm scales."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        done = set()
+        for name, t in self._params.items():
+            if id(t) in done:
+                continue
+            if name.endswith("_norm.weight"):
+                t.fill_(1.0)
+                continue
+            base = name.rsplit(".", 1)[0]
+            fan_in = self._params[f"{base}.weight"].shape[-1]
+            k = 1.0 / math.sqrt(fan_in)
+            # generate in fp32 chunks to keep the uniform unbiased after the bf16 rounding
+            flat = t.view(-1)
+            step = 1 << 26
+            for s in range(0, flat.numel(), step):
+                n = min(step, flat.numel() - s)
+                flat[s:s + n] = ((torch.rand(n, generator=g, device=self.device) * 2 - 1) * k).to(BF16)
+        return self
+
+    def sanitize(self, weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Checkpoint key mapping of the reference (flux/model.py:85-97)."""
+        new = {}
+        for k, w in weights.items():
+            if k.startswith("model.diffusion_model."):
+                k = k[22:]
+            if k.endswith(".scale"):
+                k = k[:-6] + ".weight"
+            for seq in ("img_mlp", "txt_mlp", "adaLN_modulation"):
+                if f".{seq}." in k:
+                    k = k.replace(f".{seq}.", f".{seq}.layers.")
+                    break
+            new[k] = w
+        return new
+
+    def load_weights(self, weights: Union[Dict[str, torch.Tensor], Iterable[Tuple[str, torch.Tensor]]],
+                     strict: bool = True) -> "Flux":
+        items = weights.items() if isinstance(weights, dict) else weights
+        seen = set()
+        for k, w in items:
+            if k not in self._params:
+                if strict:
+                    raise ValueError(f"Unexpected parameter {k}")
+                continue
+            dst = self._params[k]
+            if tuple(dst.shape) != tuple(w.shape):
+                raise ValueError(f"Shape mismatch for {k}: expected {tuple(dst.shape)}, got {tuple(w.shape)}")
+            dst.copy_(w.to(device=self.device, dtype=BF16))
+            seen.add(k)
+        if strict:
+            missing = set(self._params) - seen
+            if missing:
+                raise ValueError(f"Missing parameters: {sorted(missing)[:5]} ...")
+        return self
+
+    # ------------------------------------------------------------------ workspace + launch plan
+    def _workspace(self, B: int, S: int, L: int) -> dict:
+        key = (B, S, L)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        P, D, dev = self.params, self.params.hidden_size, self.device
+        mlp = int(D * P.mlp_ratio)
+        T, H = S + L, P.num_heads
+        Tpad = (T + 63) // 64 * 64
+
+        def buf(*shape, dtype=BF16):
+            return torch.empty(*shape, dtype=dtype, device=dev)
+
+        ws = dict(
+            B=B, S=S, L=L, T=T, Tpad=Tpad,
+            in_img=buf(B, L, P.in_channels), in_txt=buf(B, S, P.context_in_dim), in_y=buf(B, P.vec_in_dim),
+            in_t=buf(B), in_g=buf(B), in_ids=buf(B, T, 3, dtype=torch.int32),
+            temb=buf(B, 256), h1=buf(B, D), vec=buf(B, D), mods=buf(B, self.mod_rows),
+            x=buf(B, T, D), xm=buf(B, T, D), qkv=buf(B, T, 3 * D), attn=buf(B, T, D), hmlp=buf(B, T, mlp),
+            cat=buf(B, T, D + mlp), Q=buf(B, H, T, 128), K=buf(B, H, T, 128), Vt=buf(B, H, 128, Tpad),
+            rope=buf(B, T, 64, 2), xl=buf(B, L, D), pred=buf(B, L, P.in_channels),
+        )
+        ws["plan"] = self._build_plan(ws)
+        self._ws[key] = ws
+        return ws
+
+    def _build_plan(self, ws: dict) -> list:
+        """The fixed sequence of libfluxhip launches of one Flux forward (flux/model.py:112-136)."""
+        lib = _lib.load()
+        P, D, Wt = self.params, self.params.hidden_size, self._params
+        mlp = int(D * P.mlp_ratio)
+        B, S, L, T, Tpad, H = ws["B"], ws["S"], ws["L"], ws["T"], ws["Tpad"], P.num_heads
+        e = 2  # bytes per bf16
+        ptr = {k: v.data_ptr() for k, v in ws.items() if isinstance(v, torch.Tensor)}
+        w = lambda n: Wt[n].data_ptr()           # noqa: E731
+        wo = lambda n: Wt[n].data_ptr() if n in Wt else None   # noqa: E731
+        mp, NM = ptr["mods"], self.mod_rows
+        plan: list = []
+        keep: list = []   # descriptors must outlive the plan
+
+        def call(fn, *args):
+            plan.append((fn, args))
+
+        def gemm(groups, nbatch, N, K, lda, ldc, epi=EPI_BIAS, **kw):
+            d = make_gemm_desc(groups, nbatch, N, K, lda, ldc, epi, **kw)
+            keep.append(d)
+            call(lib.fluxhip_gemm_bf16, ctypes.byref(d))
+
+        def small(x, wn, out, K, N, silu_in, accum):
+            call(lib.fluxhip_small_linear_bf16, x, w(wn + ".weight"), wo(wn + ".bias"), out, B, N, K, silu_in, accum)
+
+        # vec = time_in(temb(t)) [+ guidance_in(temb(g))] + vector_in(y)      flux/model.py:113-120
+        call(lib.fluxhip_timestep_embedding_bf16, ptr["in_t"], ptr["temb"], B, 256, 1000.0, 10000.0)
+        small(ptr["temb"], "time_in.in_layer", ptr["h1"], 256, D, 0, 0)
+        small(ptr["h1"], "time_in.out_layer", ptr["vec"], D, D, 1, 0)
+        if P.guidance_embed:
+            call(lib.fluxhip_timestep_embedding_bf16, ptr["in_g"], ptr["temb"], B, 256, 1000.0, 10000.0)
+            small(ptr["temb"], "guidance_in.in_layer", ptr["h1"], 256, D, 0, 0)
+            small(ptr["h1"], "guidance_in.out_layer", ptr["vec"], D, D, 1, 1)
+        small(ptr["in_y"], "vector_in.in_layer", ptr["h1"], P.vec_in_dim, D, 0, 0)
+        small(ptr["h1"], "vector_in.out_layer", ptr["vec"], D, D, 1, 1)
+        # every Modulation.lin(silu(vec)) of the step in one launch            flux/layers.py:136-137
+        call(lib.fluxhip_small_linear_bf16, ptr["vec"], self.mod_w.data_ptr(), self.mod_b.data_ptr(), mp, B, NM, D, 1, 0)
+        # pe = EmbedND(ids)                                                    flux/model.py:123-124
+        call(lib.fluxhip_rope_table_bf16, ptr["in_ids"], ptr["rope"], B * T, 3, P.axes_dim[0], P.axes_dim[1],
+             P.axes_dim[2], float(P.theta))
+        # txt_in / img_in write straight into the packed token buffer          flux/model.py:112,121
+        if S > 0:
+            gemm([dict(A=ptr["in_txt"], W=w("txt_in.weight"), bias=wo("txt_in.bias"), C=ptr["x"],
+                       a_bstride=S * P.context_in_dim, c_bstride=T * D, M=S)], B, D, P.context_in_dim,
+                 P.context_in_dim, D)
+        gemm([dict(A=ptr["in_img"], W=w("img_in.weight"), bias=wo("img_in.bias"), C=ptr["x"] + S * D * e,
+                   a_bstride=L * P.in_channels, c_bstride=T * D, M=L)], B, D, P.in_channels, P.in_channels, D)
+
+        def two_streams(A, lda, a_bs, C, ldc, c_bs, wname, M_txt_rows=S, res=None, gate_off=None, i_off=0, t_off=0,
+                        prefix=""):
+            """txt group (rows [0,S)) + img group (rows [S,T)) of one double-block Linear."""
+            gs = []
+            for st, row0, M, moff in (("txt", 0, S, t_off), ("img", S, L, i_off)):
+                if M == 0:
+                    continue
+                g = dict(A=A + row0 * lda * e, W=w(f"{prefix}.{st}_{wname}.weight"), bias=wo(f"{prefix}.{st}_{wname}.bias"),
+                         C=C + row0 * ldc * e, a_bstride=a_bs, c_bstride=c_bs, M=M)
+                if res is not None:
+                    g.update(res=res + row0 * ldc * e, gate=mp + (moff + gate_off) * e, gate_bstride=NM)
+                gs.append(g)
+            return gs
+
+        for i in range(P.depth):                                              # flux/layers.py:181-231
+            p = f"double_blocks.{i}"
+            io, to = self.mod_off[f"{p}.img_mod.lin"], self.mod_off[f"{p}.txt_mod.lin"]
+            call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, S, T * D, T * D,
+                 mp + to * e, mp + (to + D) * e, mp + io * e, mp + (io + D) * e, NM, 1e-6)
+            gemm(two_streams(ptr["xm"], D, T * D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", prefix=p), B, 3 * D, D, D, 3 * D)
+            call(lib.fluxhip_qk_norm_rope_bf16, ptr["qkv"], 3 * D, B, T, S, H,
+                 wo(f"{p}.txt_attn.norm.query_norm.weight"), wo(f"{p}.txt_attn.norm.key_norm.weight"),
+                 w(f"{p}.img_attn.norm.query_norm.weight"), w(f"{p}.img_attn.norm.key_norm.weight"),
+                 ptr["rope"], T * 128, ptr["Q"], ptr["K"], ptr["Vt"], Tpad, 1e-5)
+            call(lib.fluxhip_attention_d128_bf16, ptr["Q"], ptr["K"], ptr["Vt"], ptr["attn"], D, B, H, T, Tpad,
+                 128 ** -0.5)
+            gemm(two_streams(ptr["attn"], D, T * D, ptr["x"], D, T * D, "attn.proj", res=ptr["x"], gate_off=2 * D,
+                             i_off=io, t_off=to, prefix=p), B, D, D, D, D, EPI_GATE_RES)
+            call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, S, T * D, T * D,
+                 mp + (to + 3 * D) * e, mp + (to + 4 * D) * e, mp + (io + 3 * D) * e, mp + (io + 4 * D) * e, NM, 1e-6)
+            gemm(two_streams(ptr["xm"], D, T * D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", prefix=p), B, mlp, D, D, mlp,
+                 EPI_GELU_TANH)
+            gemm(two_streams(ptr["hmlp"], mlp, T * mlp, ptr["x"], D, T * D, "mlp.layers.2", res=ptr["x"], gate_off=5 * D,
+                             i_off=io, t_off=to, prefix=p), B, D, mlp, mlp, D, EPI_GATE_RES)
+
+        for i in range(P.depth_single_blocks):                                # flux/layers.py:262-284
+            p = f"single_blocks.{i}"
+            o = self.mod_off[f"{p}.modulation.lin"]
+            call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, 0, T * D, T * D,
+                 None, None, mp + o * e, mp + (o + D) * e, NM, 1e-6)
+            gemm([dict(A=ptr["xm"], W=w(f"{p}.linear1.weight"), bias=wo(f"{p}.linear1.bias"), C=ptr["qkv"],
+                       a_bstride=T * D, c_bstride=T * 3 * D, M=T)], B, 3 * D + mlp, D, D, 3 * D, EPI_SPLIT_GELU,
+                 n_split=3 * D, C2=ptr["cat"], ldc2=D + mlp, c2_bstride=T * (D + mlp), c2_coloff=D)
+            call(lib.fluxhip_qk_norm_rope_bf16, ptr["qkv"], 3 * D, B, T, 0, H, None, None,
+                 w(f"{p}.norm.query_norm.weight"), w(f"{p}.norm.key_norm.weight"),
+                 ptr["rope"], T * 128, ptr["Q"], ptr["K"], ptr["Vt"], Tpad, 1e-5)
+            call(lib.fluxhip_attention_d128_bf16, ptr["Q"], ptr["K"], ptr["Vt"], ptr["cat"], D + mlp, B, H, T, Tpad,
+                 128 ** -0.5)
+            gemm([dict(A=ptr["cat"], W=w(f"{p}.linear2.weight"), bias=wo(f"{p}.linear2.bias"), C=ptr["x"], res=ptr["x"],
+                       gate=mp + (o + 2 * D) * e, gate_bstride=NM, a_bstride=T * (D + mlp), c_bstride=T * D, M=T)],
+                 B, D, D + mlp, D + mlp, D, EPI_GATE_RES)
+
+        # LastLayer on the img rows                                           flux/layers.py:298-302
+        o = self.mod_off["final_layer.adaLN_modulation.layers.1"]
+        call(lib.fluxhip_ln_modulate_bf16, ptr["x"] + S * D * e, ptr["xl"], B, L, D, 0, T * D, L * D,
+             None, None, mp + o * e, mp + (o + D) * e, NM, 1e-6)
+        gemm([dict(A=ptr["xl"], W=w("final_layer.linear.weight"), bias=wo("final_layer.linear.bias"), C=ptr["pred"],
+                   M=B * L)], 1, P.in_channels, D, D, P.in_channels)
+        plan.append(("keepalive", keep))
+        return plan
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, img: torch.Tensor, img_ids: torch.Tensor, txt: torch.Tensor, txt_ids: torch.Tensor,
+                 timesteps: torch.Tensor, y: torch.Tensor, guidance: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if img.ndim != 3 or txt.ndim != 3:
+            raise ValueError("Input img and txt tensors must have 3 dimensions.")
+        if self.params.guidance_embed and guidance is None:
+            raise ValueError("Didn't get guidance strength for guidance distilled model.")
+        B, L, _ = img.shape
+        S = txt.shape[1]
+        ws = self._workspace(B, S, L)
+        ws["in_img"].copy_(img)
+        ws["in_txt"].copy_(txt)
+        ws["in_y"].copy_(y)
+        ws["in_t"].copy_(timesteps)
+        if guidance is not None:
+            ws["in_g"].copy_(guidance)
+        if S > 0:
+            ws["in_ids"][:, :S].copy_(txt_ids)
+        ws["in_ids"][:, S:].copy_(img_ids)
+        self.run_plan(ws)
+        return ws["pred"].clone()
+
+    def profile_plan(self, ws: dict) -> list:
+        """Run the plan eagerly with a HIP event pair around every launch (events are recorded on the
+        stream the kernels are launched on).  Returns [(kernel label, ms, flops)] in launch order;
+        GEMM labels carry the tile configuration the library selected."""
+        lib = _lib.load()
+        stream = torch.cuda.current_stream()
+        recs = []
+        for fn, args in ws["plan"]:
+            if fn == "keepalive":
+                continue
+            label, flops = fn.__name__, 0.0
+            if fn.__name__ == "fluxhip_gemm_bf16":
+                d = args[0]._obj
+                m_total = sum(d.g[i].M for i in range(d.ngroups)) * d.nbatch
+                flops = 2.0 * m_total * d.N * d.K
+                label = f"fluxhip_gemm_bf16/cfg{lib.fluxhip_gemm_tile_cfg(args[0])}"
+            elif fn.__name__ == "fluxhip_attention_d128_bf16":
+                Bq, Hq, Tq = args[5], args[6], args[7]
+                flops = 4.0 * Bq * Hq * Tq * Tq * 128
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = fn(*args, stream.cuda_stream)
+            e1.record(stream)
+            if rc != 0:
+                raise FluxHipError(f"{fn.__name__} failed with code {rc}")
+            recs.append((label, e0, e1, flops))
+        torch.cuda.synchronize()
+        return [(l, e0.elapsed_time(e1), f) for l, e0, e1, f in recs]
+
+    def run_plan(self, ws: dict) -> None:
+        stream = torch.cuda.current_stream().cuda_stream
+        for fn, args in ws["plan"]:
+            if fn == "keepalive":
+                continue
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise FluxHipError(f"{fn.__name__} failed with code {rc}")

@@ -1,0 +1,248 @@
+"""Torch-tensor front end of the libfluxhip C ABI.
+
+torch is used only for device memory and the current HIP stream; every computation below is a
+hand-written gfx950 kernel launched through ctypes.  All tensors must be CUDA(HIP) tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc
+
+EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU = 0, 1, 2, 3, 4
+BF16 = torch.bfloat16
+
+
+class FluxHipError(RuntimeError):
+    pass
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise FluxHipError("libfluxhip ops need device tensors (no CPU fallback exists)")
+    return t.data_ptr()
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise FluxHipError(f"{what} failed with code {rc} ({'bad argument' if rc == -1 else 'launch failure'})")
+
+
+def _bf16c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != BF16 or not t.is_contiguous():
+        raise FluxHipError(f"{name} must be a contiguous bfloat16 tensor")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(desc: GemmDesc) -> None:
+    _check(_lib.load().fluxhip_gemm_bf16(desc, _stream()), "fluxhip_gemm_bf16")
+
+
+def make_gemm_desc(groups: Sequence[dict], nbatch: int, N: int, K: int, lda: int, ldc: int, epi: int = EPI_BIAS,
+                   n_split: int = 0, C2: Optional[int] = None, ldc2: int = 0, c2_bstride: int = 0,
+                   c2_coloff: int = 0, row_bias: bool = False, alpha: float = 1.0, tile_cfg: int = 0, out_f32: bool = False) -> GemmDesc:
+    """groups: dicts of raw device addresses: A, W, bias, C, res, gate (ints or None) + a_bstride,
+    c_bstride, gate_bstride, M."""
+    d = GemmDesc()
+    d.ngroups, d.nbatch, d.N, d.K, d.lda, d.ldc, d.epi = len(groups), nbatch, N, K, lda, ldc, epi
+    d.row_bias, d.n_split, d.ldc2, d.C2, d.c2_bstride, d.c2_coloff = int(row_bias), n_split, ldc2, C2, c2_bstride, c2_coloff
+    d.tile_cfg, d.alpha, d.out_f32 = tile_cfg, alpha, int(out_f32)
+    for i, g in enumerate(groups):
+        t = d.g[i]
+        t.A, t.W, t.bias, t.C = g["A"], g["W"], g.get("bias"), g["C"]
+        t.res, t.gate = g.get("res"), g.get("gate")
+        t.a_bstride, t.c_bstride, t.gate_bstride = g.get("a_bstride", 0), g.get("c_bstride", 0), g.get("gate_bstride", 0)
+        t.M = g["M"]
+    return d
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, epi: int = EPI_BIAS,
+           out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+           gate: Optional[torch.Tensor] = None, tile_cfg: int = 0) -> torch.Tensor:
+    """y = epi(x @ w.T + b) for x [..., K], w [N, K]; gate [N] (broadcast over rows) optional."""
+    _bf16c(x, "x"); _bf16c(w, "w")
+    K = x.shape[-1]
+    N = w.shape[0]
+    M = x.numel() // K
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=BF16, device=x.device)
+    g = dict(A=_p(x), W=_p(w), bias=_p(b), C=_p(out), res=_p(res), gate=_p(gate), M=M)
+    gemm(make_gemm_desc([g], 1, N, K, K, N, epi, tile_cfg=tile_cfg))
+    return out
+
+
+def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+                 silu_in: bool = False, accum: bool = False) -> torch.Tensor:
+    _bf16c(x, "x"); _bf16c(w, "w")
+    B, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        if accum:
+            raise FluxHipError("accum needs an existing output")
+        out = torch.empty(B, N, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_small_linear_bf16(_p(x), _p(w), _p(b), _p(out), B, N, K, int(silu_in), int(accum),
+                                                  _stream()), "fluxhip_small_linear_bf16")
+    return out
+
+
+def ln_modulate(x: torch.Tensor, out: torch.Tensor, B: int, Tr: int, D: int, S: int, x_bstride: int, out_bstride: int,
+                shift_txt, scale_txt, shift_img, scale_img, mod_bstride: int, eps: float = 1e-6) -> None:
+    """shift/scale arguments are raw device addresses (views into the per-step modulation table)."""
+    _check(_lib.load().fluxhip_ln_modulate_bf16(_p(x) if isinstance(x, torch.Tensor) else x,
+                                                 _p(out) if isinstance(out, torch.Tensor) else out,
+                                                 B, Tr, D, S, x_bstride, out_bstride, shift_txt, scale_txt, shift_img,
+                                                 scale_img, mod_bstride, eps, _stream()), "fluxhip_ln_modulate_bf16")
+
+
+def qk_norm_rope(qkv: torch.Tensor, ld: int, B: int, T: int, S: int, H: int, qw_txt, kw_txt, qw_img, kw_img,
+                 rope: torch.Tensor, rope_bstride: int, Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, Tpad: int,
+                 eps: float = 1e-5) -> None:
+    _check(_lib.load().fluxhip_qk_norm_rope_bf16(_p(qkv), ld, B, T, S, H, _p(qw_txt), _p(kw_txt), _p(qw_img),
+                                                  _p(kw_img), _p(rope), rope_bstride, _p(Q), _p(K), _p(Vt), Tpad, eps,
+                                                  _stream()), "fluxhip_qk_norm_rope_bf16")
+
+
+def attention_d128(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, O, ldo: int, B: int, H: int, T: int, Tpad: int,
+                   scale: float) -> None:
+    _check(_lib.load().fluxhip_attention_d128_bf16(_p(Q), _p(K), _p(Vt), _p(O) if isinstance(O, torch.Tensor) else O,
+                                                    ldo, B, H, T, Tpad, scale, _stream()), "fluxhip_attention_d128_bf16")
+
+
+def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 10000.0, time_factor: float = 1000.0):
+    _bf16c(t, "t")
+    out = torch.empty(t.shape[0], dim, dtype=BF16, device=t.device)
+    _check(_lib.load().fluxhip_timestep_embedding_bf16(_p(t), _p(out), t.shape[0], dim, time_factor, max_period,
+                                                        _stream()), "fluxhip_timestep_embedding_bf16")
+    return out
+
+
+def rope_table(ids: torch.Tensor, axes_dim: Sequence[int], theta: float) -> torch.Tensor:
+    """ids int32 [..., 3] -> bf16 [..., sum(axes)/2, 2] (cos, sin)."""
+    if ids.dtype != torch.int32 or not ids.is_contiguous() or ids.shape[-1] != 3:
+        raise FluxHipError("ids must be contiguous int32 [..., 3]")
+    ntok = ids.numel() // 3
+    out = torch.empty(*ids.shape[:-1], sum(axes_dim) // 2, 2, dtype=BF16, device=ids.device)
+    _check(_lib.load().fluxhip_rope_table_bf16(_p(ids), _p(out), ntok, 3, axes_dim[0], axes_dim[1], axes_dim[2],
+                                                float(theta), _stream()), "fluxhip_rope_table_bf16")
+    return out
+
+
+def euler_step(x: torch.Tensor, pred: torch.Tensor, dt: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16c(x, "x"); _bf16c(pred, "pred")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(_lib.load().fluxhip_euler_step_bf16(_p(x), _p(pred), _p(out), x.numel(), float(dt), _stream()),
+           "fluxhip_euler_step_bf16")
+    return out
+
+
+def pack_latents(x: torch.Tensor) -> torch.Tensor:
+    _bf16c(x, "x")
+    B, h, w, c = x.shape
+    out = torch.empty(B, (h // 2) * (w // 2), c * 4, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_pack_latents_bf16(_p(x), _p(out), B, h, w, c, _stream()), "fluxhip_pack_latents_bf16")
+    return out
+
+
+def unpack_latents(x: torch.Tensor, h: int, w: int, scale: float = 1.0, shift: float = 0.0) -> torch.Tensor:
+    _bf16c(x, "x")
+    B = x.shape[0]
+    c = x.shape[-1] // 4
+    out = torch.empty(B, h, w, c, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_unpack_latents_bf16(_p(x), _p(out), B, h, w, c, float(scale), float(shift), _stream()),
+           "fluxhip_unpack_latents_bf16")
+    return out
+
+
+_zero16 = {}
+
+
+def _zeros16(device) -> torch.Tensor:
+    z = _zero16.get(device)
+    if z is None:
+        z = torch.zeros(64, dtype=BF16, device=device)
+        _zero16[device] = z
+    return z
+
+
+def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], stride: int = 1, pad: int = 1, ups: bool = False,
+           res: Optional[torch.Tensor] = None, epi: int = EPI_BIAS, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC conv, w [Cout,kh,kw,Cin] (or [Cout,Cin] for 1x1). res => out = res + conv(x)."""
+    _bf16c(x, "x"); _bf16c(w, "w")
+    B, Hs, Ws, Cin = x.shape
+    Cout = w.shape[0]
+    ks = 1 if w.dim() == 2 else w.shape[1]
+    if ks == 1:
+        pad = 0
+    Hl, Wl = (Hs * 2, Ws * 2) if ups else (Hs, Ws)
+    Ho, Wo = (Hl + 2 * pad - ks) // stride + 1, (Wl + 2 * pad - ks) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, Cout, dtype=BF16, device=x.device)
+    if res is not None:
+        epi = EPI_GATE_RES
+    lib = _lib.load()
+    if Cin % 64 == 0 and Cout % 4 == 0:
+        _check(lib.fluxhip_conv2d_bf16(_p(x), _p(w), _p(b), _p(res), _p(out), B, Hs, Ws, Cin, Cout, ks, stride, pad,
+                                       int(ups), epi, _p(_zeros16(x.device)), _stream()), "fluxhip_conv2d_bf16")
+    else:
+        if ks != 3 or stride != 1 or pad != 1 or ups or res is not None:
+            raise FluxHipError("small-channel conv path only supports 3x3/s1/p1")
+        _check(lib.fluxhip_conv2d_small(_p(x), _p(w), _p(b), _p(out), B, Hs, Ws, Cin, Cout, 0, 0, _stream()),
+               "fluxhip_conv2d_small")
+    return out
+
+
+def conv2d_out_image(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], clip01: bool) -> torch.Tensor:
+    """Final decoder conv (Cout=3) -> float32 NHWC image, optionally clip(y+1,0,2)*0.5."""
+    _bf16c(x, "x"); _bf16c(w, "w")
+    B, H, W_, Cin = x.shape
+    Cout = w.shape[0]
+    out = torch.empty(B, H, W_, Cout, dtype=torch.float32, device=x.device)
+    _check(_lib.load().fluxhip_conv2d_small(_p(x), _p(w), _p(b), _p(out), B, H, W_, Cin, Cout, 1, int(clip01),
+                                             _stream()), "fluxhip_conv2d_small")
+    return out
+
+
+_gn_ws = {}
+
+
+def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6,
+                   silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16c(x, "x")
+    B, H, W_, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    ws = _gn_ws.get(x.device)
+    need = B * ((H * W_ + 31) // 32) * groups * 2 * 4
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(max(need // 4, 1 << 18), dtype=torch.float32, device=x.device)
+        _gn_ws[x.device] = ws
+    _check(_lib.load().fluxhip_groupnorm_silu_bf16(_p(x), _p(gamma), _p(beta), _p(out), B, H * W_, Cc, groups, eps,
+                                                    int(silu), _p(ws), ws.numel() * 4, _stream()),
+           "fluxhip_groupnorm_silu_bf16")
+    return out
+
+
+def softmax_rows(s: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None,
+                 cols: Optional[int] = None) -> torch.Tensor:
+    """s float32 [..., ld] -> bf16 softmax(scale * s[..., :cols]) written to out[..., :cols]."""
+    if s.dtype != torch.float32 or not s.is_contiguous():
+        raise FluxHipError("s must be contiguous float32")
+    ld = s.shape[-1]
+    cols = ld if cols is None else cols
+    rows = s.numel() // ld
+    if out is None:
+        out = torch.zeros(s.shape, dtype=BF16, device=s.device)
+    _check(_lib.load().fluxhip_softmax_rows_f32(_p(s), _p(out), rows, cols, ld, float(scale), _stream()),
+           "fluxhip_softmax_rows_f32")
+    return out

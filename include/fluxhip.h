@@ -1,0 +1,165 @@
+/* libfluxhip — C ABI of the MI355X (gfx950) latent-diffusion denoise/decode hot path.
+ *
+ * The reference (voipnuggets/flux-generator) has no FFI/plugin layer: its hot path is
+ * Python calling MLX ops. This header is the operator boundary a maintainer would bind
+ * instead of those MLX calls (see INTEGRATION.md for the ctypes stub). Each entry point
+ * cites the reference call it replaces (paths relative to the reference tree).
+ *
+ * Conventions (inner seam):
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors on the Python side);
+ *   - bf16 tensors are raw uint16 bfloat16, row-major, last dim contiguous;
+ *   - no allocation, no implicit synchronisation: work is enqueued on `stream` (hipStream_t);
+ *   - return 0 on success, negative on error (-1 bad argument, -2 launch failure); never throws;
+ *   - thread-safe iff callers use distinct streams / output buffers.
+ */
+#ifndef FLUXHIP_H
+#define FLUXHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUXHIP_ABI_VERSION 1
+
+int fluxhip_abi_version(void);
+/* "gfx950" — the only architecture this library is built for. */
+const char* fluxhip_arch(void);
+
+/* ---- epilogues of fluxhip_gemm_bf16 ------------------------------------------------ */
+enum {
+  FLUXHIP_EPI_BIAS = 0,       /* C = A W^T + b                       nn.Linear                 */
+  FLUXHIP_EPI_GELU_TANH = 1,  /* C = gelu_tanh(A W^T + b)            nn.GELU(approx="tanh")    */
+  FLUXHIP_EPI_GATE_RES = 2,   /* C = res + gate * (A W^T + b)        x + mod.gate * proj(...)  */
+  FLUXHIP_EPI_SPLIT_GELU = 3, /* cols <  n_split -> C ; cols >= n_split -> gelu_tanh -> C2     */
+  FLUXHIP_EPI_SILU = 4        /* C = silu(A W^T + b)                                            */
+};
+
+/* One operand group of a (possibly grouped) GEMM. Two groups share N, K, the epilogue and the
+ * launch: this is how the txt and img streams of a DoubleStreamBlock (different weights, same
+ * shapes; flux/layers.py:192-208,220-229) run as ONE launch over the packed [txt;img] buffer. */
+typedef struct fluxhip_gemm_group {
+  const void* A;         /* bf16 [nbatch][M][lda]                                         */
+  const void* W;         /* bf16 [N][K]  (nn.Linear weight layout, [out,in])              */
+  const void* bias;      /* bf16 [N] or NULL                                              */
+  void* C;               /* bf16 [nbatch][M][ldc]                                         */
+  const void* res;       /* bf16 residual, indexed like C (EPI_GATE_RES; may alias C)     */
+  const void* gate;      /* bf16 [nbatch][gate_bstride] or NULL (EPI_GATE_RES)            */
+  int64_t a_bstride;     /* elements between batches of A                                 */
+  int64_t c_bstride;     /* elements between batches of C / res                           */
+  int64_t gate_bstride;  /* elements between batches of gate                              */
+  int32_t M;             /* rows per batch                                                */
+  int32_t _pad;
+} fluxhip_gemm_group;
+
+typedef struct fluxhip_gemm_desc {
+  fluxhip_gemm_group g[2];
+  int32_t ngroups;       /* 1 or 2                                                        */
+  int32_t nbatch;
+  int32_t N, K;          /* K % 64 == 0, N % 4 == 0                                       */
+  int32_t lda, ldc;      /* row strides (elements), multiples of 8 / 4                    */
+  int32_t epi;           /* FLUXHIP_EPI_*                                                 */
+  int32_t row_bias;      /* bias indexed by output row (used for V^T = Wv Y^T)            */
+  int32_t n_split;       /* EPI_SPLIT_GELU                                                */
+  int32_t ldc2;
+  void* C2;
+  int64_t c2_bstride;
+  int32_t c2_coloff;
+  int32_t tile_cfg;      /* 0 = auto; otherwise index into the compiled tile configs      */
+  float alpha;           /* acc scale before bias (1.0 for Linear; 0 means 1.0)           */
+  int32_t out_f32;       /* EPI_BIAS only: C is float32 [..][ldc] (VAE attention logits)  */
+} fluxhip_gemm_desc;
+
+/* Replaces nn.Linear (+ fused activation / gated residual) on the Flux path:
+ * flux/layers.py:104,106 (qkv, proj), :163-165,176-178 (MLP), :250,252 (linear1/linear2),
+ * :295 (final linear); flux/model.py:56,64 (img_in, txt_in). */
+int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream);
+/* Introspection for profiling/bench: which compiled tile configuration fluxhip_gemm_bf16 uses for
+ * `d` (>= 1), and that configuration's block tile / threads. No device work. */
+int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d);
+int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads);
+
+/* Implicit-GEMM convolution, NHWC bf16, weight [Cout][kh][kw][Cin] (MLX nn.Conv2d layout).
+ * ksize 1|3, stride 1|2, pad 0|1, ups=1 fuses upsample_nearest(x,(2,2)) into the loader.
+ * out = epi(conv(x) + bias [+ res]).  Replaces nn.Conv2d / Upsample in
+ * flux/autoencoder.py:70-81,117-122,224-226,269 and the UNet/VAE convs of stable_diffusion/.
+ * Cin % 64 == 0, Cout % 4 == 0 (the 16->512 conv_in and 128->3 conv_out use the two
+ * dedicated entry points below). */
+int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bias, const void* res, void* out,
+                        int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int pad,
+                        int ups, int epi, const void* zero16, void* stream);
+/* Direct conv for tiny channel counts (Cin*9 not a multiple of 64, or Cout < 4). fp32 accumulate.
+ * out_f32 != 0 writes float32 (the decoder's final image), optionally clip((y+1),0,2)*0.5
+ * (flux/flux.py:162) when clip01 != 0. */
+int fluxhip_conv2d_small(const void* x, const void* w, const void* bias, void* out, int B, int H,
+                         int W, int Cin, int Cout, int out_f32, int clip01, void* stream);
+
+/* Small-M linear (M = batch <= 16): out[b,n] = (accum ? out[b,n] : 0) + x'[b,:] . W[n,:] + bias[n],
+ * x' = silu(x) when silu_in. HBM-bound on W. Replaces MLPEmbedder (flux/layers.py:78-85) and every
+ * Modulation.lin (flux/layers.py:134-137) — all 95 modulation layers of a step run as ONE call on
+ * the row-concatenated weight. */
+int fluxhip_small_linear_bf16(const void* x, const void* W, const void* bias, void* out, int B,
+                              int N, int K, int silu_in, int accum, void* stream);
+
+/* out = (1 + scale) * LayerNorm(x, eps, no affine) + shift over rows of width D (D % 8 == 0,
+ * D <= 4096).  B batches of Tr rows; row (b,t) is read at x + b*x_bstride + t*D and written at
+ * out + b*out_bstride + t*D.  Rows t < S use the txt shift/scale, the others img; each is a
+ * per-batch vector ([B][mod_bstride]).  Replaces nn.LayerNorm(affine=False) + modulate at
+ * flux/layers.py:192-193,202-203,222,228,267,300. */
+int fluxhip_ln_modulate_bf16(const void* x, void* out, int B, int Tr, int D, int S,
+                             int64_t x_bstride, int64_t out_bstride, const void* shift_txt,
+                             const void* scale_txt, const void* shift_img, const void* scale_img,
+                             int64_t mod_bstride, float eps, void* stream);
+
+/* QKNorm (RMSNorm over head_dim=128, learned scale; flux/layers.py:88-95) + RoPE
+ * (flux/layers.py:29-33) on q,k, plus the V transpose the attention kernel wants.
+ * qkv: bf16 [B*T][ld], q at col 0, k at col H*128, v at col 2*H*128 (head-major inside each).
+ * rope: bf16 [T][64][2] = (cos, sin) per rotation pair (already rounded to bf16 like the
+ * reference's pe.astype(bf16), flux/model.py:124); batch b reads rope + b*rope_bstride (0 = shared).
+ * Outputs: Q,K bf16 [B][H][T][128]; Vt bf16 [B][H][128][Tpad] with zero padding for t >= T. */
+int fluxhip_qk_norm_rope_bf16(const void* qkv, int ld, int B, int T, int S, int H,
+                              const void* qw_txt, const void* kw_txt, const void* qw_img,
+                              const void* kw_img, const void* rope, int64_t rope_bstride, void* Q,
+                              void* Kout, void* Vt, int Tpad, float eps, void* stream);
+
+/* Joint (txt+img) non-causal attention, head_dim 128: O[b,t,h*128:(h+1)*128] =
+ * softmax(scale * Q K^T) V.  Replaces mx.fast.scaled_dot_product_attention + the
+ * transpose/reshape at flux/layers.py:36-43.  O is token-major with row stride ldo. */
+int fluxhip_attention_d128_bf16(const void* Q, const void* K, const void* Vt, void* O, int ldo,
+                                int B, int H, int T, int Tpad, float scale, void* stream);
+
+/* timestep_embedding(t, dim) (flux/layers.py:46-57) for a bf16 timestep vector t[B]:
+ * out[b] = [cos(a) | sin(a)], a = bf16(time_factor * t[b]) * exp(-ln(max_period) * k / (dim/2)). */
+int fluxhip_timestep_embedding_bf16(const void* t, void* out, int B, int dim, float time_factor,
+                                    float max_period, void* stream);
+
+/* EmbedND (flux/layers.py:60-75) reduced to what attention needs: ids int32 [ntok][3] ->
+ * out bf16 [ntok][(a0+a1+a2)/2][2] = (cos, sin) of ids[axis] * theta^(-2j/a_axis). */
+int fluxhip_rope_table_bf16(const void* ids, void* out, int64_t ntok, int n_axes, int a0, int a1,
+                            int a2, float theta, void* stream);
+
+/* x_out = x + dt * pred  (bf16; FluxSampler.step, flux/sampler.py:56-57). */
+int fluxhip_euler_step_bf16(const void* x, const void* pred, void* out, int64_t n, float dt,
+                            void* stream);
+
+/* 2x2 pixel-unshuffle pack [B,h,w,C] -> [B,(h/2)(w/2),4C] (flux/flux.py:57-58) and its inverse
+ * (flux/flux.py:159-160).  Packed feature index = c*4 + dy*2 + dx. */
+int fluxhip_pack_latents_bf16(const void* x, void* out, int B, int h, int w, int C, void* stream);
+int fluxhip_unpack_latents_bf16(const void* x, void* out, int B, int h, int w, int C, float scale,
+                                float shift, void* stream);
+
+/* GroupNorm(G groups, eps, affine) [+ SiLU] on NHWC bf16 (nn.GroupNorm(pytorch_compatible=True),
+ * flux/autoencoder.py:29-35,62-78,266).  ws: float workspace >= B*G*2*nchunks floats.
+ * Two launches (partial statistics, then normalise) on `stream`. */
+int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, const void* beta, void* out,
+                                int B, int HW, int C, int G, float eps, int silu, void* ws,
+                                int64_t ws_bytes, void* stream);
+
+/* Row softmax of float32 logits scaled by `scale`: P(bf16) = softmax(scale * S), fp32 inside.
+ * Used by the single-head VAE AttnBlock (flux/autoencoder.py:49).  ld: row stride of S and P. */
+int fluxhip_softmax_rows_f32(const void* s, void* p, int64_t rows, int cols, int ld, float scale,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUXHIP_H */

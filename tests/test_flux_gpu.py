@@ -1,0 +1,106 @@
+"""End-to-end parity of the HIP Flux forward / denoise loop vs the CPU oracle (tiny configs the
+oracle finishes in seconds, plus one full-width block).
+
+Tolerances (stated per SURVEY.md §8(c)): the HIP path stores bf16 between kernels and accumulates
+in fp32.  Against the oracle run in fp32 with the same (bf16-representable) weights and inputs:
+rel-L2 <= 1e-2 for one forward, <= 2e-2 on the latents after the whole loop.  Against the oracle
+run in bf16 (MLX's op-boundary rounding) the same bounds hold (both are bf16-noise-limited).
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import flux_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def tiny_params(guidance=False, depth=2, singles=3, heads=2):
+    return dict(in_channels=64, vec_in_dim=64, context_in_dim=128, hidden_size=128 * heads, mlp_ratio=4.0,
+                num_heads=heads, depth=depth, depth_single_blocks=singles, axes_dim=[16, 56, 56], theta=10_000,
+                qkv_bias=True, guidance_embed=guidance)
+
+
+def make_inputs(P, B, S, h, w, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, h, w, 16, generator=g).to(BF)
+    img, img_ids = O.prepare_latent_images(z)
+    txt = (torch.randn(B, S, P.context_in_dim, generator=g) * 0.5).to(BF)
+    txt_ids = torch.zeros(B, S, 3, dtype=torch.int32)
+    vec = torch.randn(B, P.vec_in_dim, generator=g).to(BF)
+    return img, img_ids, txt, txt_ids, vec
+
+
+def build(P_kwargs, dev, seed=0):
+    from flux_generator_amd.flux.model import Flux, FluxParams
+    OP = O.FluxParams(**P_kwargs)
+    W = O.init_weights(O.flux_weight_shapes(OP), seed=seed, dtype=torch.float32, norm_jitter=0.2)
+    W = {k: v.to(BF).float() for k, v in W.items()}          # bf16-representable weights for both sides
+    model = Flux(FluxParams(**P_kwargs), device=dev).load_weights(W)
+    return OP, W, model
+
+
+@pytest.mark.parametrize("guidance,B,S,hw", [(False, 1, 64, (16, 16)), (True, 2, 40, (12, 20)), (False, 1, 0 + 8, (6, 10))])
+def test_flux_forward_tiny(dev, guidance, B, S, hw):
+    OP, W, model = build(tiny_params(guidance), dev)
+    img, img_ids, txt, txt_ids, vec = make_inputs(OP, B, S, *hw)
+    t = torch.full((B,), 0.75, dtype=BF)
+    gd = torch.full((B,), 4.0, dtype=BF) if guidance else None
+    ref32 = O.flux_forward(OP, W, img.float(), img_ids, txt.float(), txt_ids, t, vec.float(),
+                           gd)
+    Wb = {k: v.to(BF) for k, v in W.items()}
+    ref16 = O.flux_forward(OP, Wb, img, img_ids, txt, txt_ids, t, vec, gd)
+    got = model(img.to(dev), img_ids.to(dev), txt.to(dev), txt_ids.to(dev), t.to(dev), vec.to(dev),
+                None if gd is None else gd.to(dev))
+    assert got.shape == ref32.shape and got.dtype == BF
+    e32, e16, eo = rel_l2(got, ref32), rel_l2(got, ref16), rel_l2(ref16, ref32)
+    print(f"rel-L2 hip-vs-fp32 {e32:.2e}  hip-vs-bf16 {e16:.2e}  bf16oracle-vs-fp32 {eo:.2e}")
+    assert e32 < 1e-2 and e16 < 1e-2
+
+
+def test_flux_errors(dev):
+    from flux_generator_amd.flux.model import Flux, FluxParams
+    with pytest.raises(ValueError):
+        Flux(FluxParams(**{**tiny_params(), "hidden_size": 250}), device=dev)
+    with pytest.raises(ValueError):
+        Flux(FluxParams(**{**tiny_params(), "axes_dim": [16, 56, 48]}), device=dev)
+    OP, W, model = build(tiny_params(True), dev)
+    img, img_ids, txt, txt_ids, vec = [t.to(dev) for t in make_inputs(OP, 1, 16, 8, 8)]
+    t = torch.full((1,), 1.0, dtype=BF, device=dev)
+    with pytest.raises(ValueError):
+        model(img, img_ids, txt, txt_ids, t, vec, None)            # guidance-distilled model needs guidance
+    with pytest.raises(ValueError):
+        model(img[0], img_ids, txt, txt_ids, t, vec, t)            # rank check
+
+
+def test_denoise_loop_tiny(dev):
+    """Full sampler loop (dev-style shifted schedule, 4 steps) vs the bf16 and fp32 oracles."""
+    from flux_generator_amd.flux.sampler import FluxSampler
+    OP, W, model = build(tiny_params(True, depth=2, singles=2), dev)
+    B, S, h, w = 1, 32, 16, 16
+    img, img_ids, txt, txt_ids, vec = make_inputs(OP, B, S, h, w, seed=3)
+    steps = 4
+    ref = O.denoising_loop(OP, W, "flux-dev", img.float(), img_ids, txt.float(), txt_ids, vec.float(), steps, 3.5)
+    sampler = FluxSampler("flux-dev")
+    ts = sampler.timesteps(steps, img.shape[1])
+    assert ts == O.timesteps("flux-dev", steps, img.shape[1])
+    x = img.to(dev)
+    gd = torch.full((B,), 3.5, dtype=BF, device=dev)
+    for i in range(steps):
+        tt = torch.full((B,), ts[i], dtype=BF, device=dev)
+        pred = model(x, img_ids.to(dev), txt.to(dev), txt_ids.to(dev), tt, vec.to(dev), gd)
+        x = sampler.step(pred, x, ts[i], ts[i + 1])
+        assert rel_l2(x, ref[i]) < 2e-2, f"step {i}"
+
+
+def test_full_width_blocks(dev):
+    """One double + one single block at Flux's real width (3072 = 24 x 128, MLP 12288), T = 320."""
+    OP, W, model = build(dict(in_channels=64, vec_in_dim=768, context_in_dim=4096, hidden_size=3072, mlp_ratio=4.0,
+                              num_heads=24, depth=1, depth_single_blocks=1, axes_dim=[16, 56, 56], theta=10_000,
+                              qkv_bias=True, guidance_embed=False), dev, seed=5)
+    img, img_ids, txt, txt_ids, vec = make_inputs(OP, 1, 64, 32, 32, seed=1)
+    t = torch.full((1,), 0.5, dtype=BF)
+    ref = O.flux_forward(OP, W, img.float(), img_ids, txt.float(), txt_ids, t, vec.float())
+    got = model(img.to(dev), img_ids.to(dev), txt.to(dev), txt_ids.to(dev), t.to(dev), vec.to(dev))
+    assert rel_l2(got, ref) < 1e-2

@@ -1,0 +1,252 @@
+"""Per-kernel parity: libfluxhip (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (floating point; the path computes in bf16 storage / fp32 accumulate):
+  * vs the oracle run in fp32 on the SAME bf16-rounded inputs: rel-L2 <= 4e-3 for one op
+    (bf16 output rounding alone is ~2e-3 rel-L2), exact for pure data movement;
+  * index/permutation kernels (pack / unpack) are bit-exact.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import flux_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+TOL = 4e-3
+
+
+def rnd(*shape, scale=1.0, seed=0, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(dev)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 256), (200, 136, 128), (1280, 3072, 512),
+                                   (37, 64, 64), (1024, 64, 3072)])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+def test_gemm_bias(dev, M, N, K, cfg):
+    from flux_generator_amd import ops
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    y = ops.linear(x, w, b, tile_cfg=cfg)
+    ref = O.linear(x.float().cpu(), w.float().cpu(), b.float().cpu())
+    assert rel_l2(y, ref) < TOL
+
+
+def test_gemm_is_not_transposed(dev):
+    """A = I check with an asymmetric W (catches row/col swaps of the MFMA C layout)."""
+    from flux_generator_amd import ops
+    K = 128
+    x = torch.eye(K, dtype=BF, device=dev)
+    w = (torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 251 - 125).to(BF).to(dev)
+    y = ops.linear(x, w)
+    assert torch.equal(y.float().cpu(), w.float().cpu().t())
+
+
+def test_gemm_epilogues(dev):
+    from flux_generator_amd import ops
+    M, N, K = 320, 256, 192
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    xf, wf, bf = x.float().cpu(), w.float().cpu(), b.float().cpu()
+    lin = O.linear(xf, wf, bf)
+    assert rel_l2(ops.linear(x, w, b, epi=ops.EPI_GELU_TANH), O.gelu_tanh(lin)) < TOL
+    assert rel_l2(ops.linear(x, w, b, epi=ops.EPI_SILU), O.silu(lin)) < TOL
+    res, gate = rnd(M, N, seed=4), rnd(N, seed=5)
+    out = ops.linear(x, w, b, epi=ops.EPI_GATE_RES, res=res, gate=gate)
+    assert rel_l2(out, res.float().cpu() + gate.float().cpu() * lin) < TOL
+    # in-place residual (C aliases res), as the denoise path uses it
+    buf = res.clone()
+    ops.linear(x, w, b, epi=ops.EPI_GATE_RES, out=buf, res=buf, gate=gate)
+    assert torch.equal(buf, out)
+
+
+def test_gemm_grouped_split_batched(dev):
+    """Two weight groups over one packed [txt;img] buffer, per-batch gates, split-GELU epilogue."""
+    from flux_generator_amd import ops
+    B, S, L, D, N = 2, 40, 150, 128, 256
+    T = S + L
+    x = rnd(B, T, D, seed=1)
+    wt, wi = rnd(N, D, seed=2, scale=D ** -0.5), rnd(N, D, seed=3, scale=D ** -0.5)
+    bt, bi = rnd(N, seed=4), rnd(N, seed=5)
+    out = torch.zeros(B, T, N, dtype=BF, device=dev)
+    e = 2
+    groups = [dict(A=x.data_ptr(), W=wt.data_ptr(), bias=bt.data_ptr(), C=out.data_ptr(), a_bstride=T * D,
+                   c_bstride=T * N, M=S),
+              dict(A=x.data_ptr() + S * D * e, W=wi.data_ptr(), bias=bi.data_ptr(), C=out.data_ptr() + S * N * e,
+                   a_bstride=T * D, c_bstride=T * N, M=L)]
+    ops.gemm(ops.make_gemm_desc(groups, B, N, D, D, N))
+    xf = x.float().cpu()
+    ref = torch.cat([O.linear(xf[:, :S], wt.float().cpu(), bt.float().cpu()),
+                     O.linear(xf[:, S:], wi.float().cpu(), bi.float().cpu())], dim=1)
+    assert rel_l2(out, ref) < TOL
+
+    # gated residual with per-batch gate vectors living in a wider table
+    NM = 3 * N
+    table = rnd(B, NM, seed=6)
+    res = rnd(B, T, N, seed=7)
+    buf = res.clone()
+    for g, off in zip(groups, (0, N)):
+        g.update(res=g["C"] - out.data_ptr() + buf.data_ptr(), C=g["C"] - out.data_ptr() + buf.data_ptr(),
+                 gate=table.data_ptr() + off * e, gate_bstride=NM)
+    ops.gemm(ops.make_gemm_desc(groups, B, N, D, D, N, ops.EPI_GATE_RES))
+    tb = table.float().cpu()
+    gate = torch.cat([tb[:, None, 0:N].expand(B, S, N), tb[:, None, N:2 * N].expand(B, L, N)], dim=1)
+    assert rel_l2(buf, res.float().cpu() + gate * ref) < TOL
+
+    # split epilogue: first n_split columns raw, the rest GELU'd into a second buffer at a column offset
+    n_split, off2, ld2 = 128, 64, 64 + (N - 128)
+    c1 = torch.zeros(B, T, n_split, dtype=BF, device=dev)
+    c2 = torch.zeros(B, T, ld2, dtype=BF, device=dev)
+    g = dict(A=x.data_ptr(), W=wi.data_ptr(), bias=bi.data_ptr(), C=c1.data_ptr(), a_bstride=T * D,
+             c_bstride=T * n_split, M=T)
+    ops.gemm(ops.make_gemm_desc([g], B, N, D, D, n_split, ops.EPI_SPLIT_GELU, n_split=n_split, C2=c2.data_ptr(),
+                                ldc2=ld2, c2_bstride=T * ld2, c2_coloff=off2))
+    full = O.linear(xf, wi.float().cpu(), bi.float().cpu())
+    assert rel_l2(c1, full[..., :n_split]) < TOL
+    assert rel_l2(c2[..., off2:], O.gelu_tanh(full[..., n_split:])) < TOL
+    assert torch.count_nonzero(c2[..., :off2]) == 0
+
+
+def test_gemm_bad_args(dev):
+    from flux_generator_amd import ops
+    x, w = rnd(64, 72), rnd(64, 72)   # K % 64 != 0 -> -1, raised as FluxHipError
+    with pytest.raises(ops.FluxHipError):
+        ops.linear(x, w)
+
+
+# ------------------------------------------------------------------ small linear
+@pytest.mark.parametrize("B,N,K", [(1, 3072, 256), (1, 1030, 768), (3, 513, 3072), (8, 256, 128)])
+@pytest.mark.parametrize("silu_in", [False, True])
+def test_small_linear(dev, B, N, K, silu_in):
+    from flux_generator_amd import ops
+    x, w, b = rnd(B, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    y = ops.small_linear(x, w, b, silu_in=silu_in)
+    xi = x.float().cpu()
+    if silu_in:
+        xi = O.silu(x.cpu()).float()      # silu output is a bf16 tensor in the reference
+    ref = O.linear(xi, w.float().cpu(), b.float().cpu())
+    assert rel_l2(y, ref) < TOL
+    prev = rnd(B, N, seed=9)
+    acc = ops.small_linear(x, w, b, out=prev.clone(), silu_in=silu_in, accum=True)
+    assert rel_l2(acc, prev.float().cpu() + ref) < TOL
+
+
+# ------------------------------------------------------------------ adaLN
+@pytest.mark.parametrize("D", [256, 384, 3072])
+def test_ln_modulate(dev, D):
+    from flux_generator_amd import ops
+    B, S, L = 2, 5, 11
+    T = S + L
+    x = rnd(B, T, D, seed=1, scale=3.0) + 0.5
+    mods = rnd(B, 4 * D, seed=2, scale=0.3)
+    out = torch.empty_like(x)
+    mp, e = mods.data_ptr(), 2
+    ops.ln_modulate(x, out, B, T, D, S, T * D, T * D, mp, mp + D * e, mp + 2 * D * e, mp + 3 * D * e, 4 * D)
+    xf, m = x.float().cpu(), mods.float().cpu()
+    ln = O.layer_norm(xf)
+    ref = torch.cat([(1 + m[:, None, D:2 * D]) * ln[:, :S] + m[:, None, 0:D],
+                     (1 + m[:, None, 3 * D:]) * ln[:, S:] + m[:, None, 2 * D:3 * D]], dim=1)
+    assert rel_l2(out, ref) < 6e-3   # four bf16 op-boundary roundings are reproduced inside the kernel
+    # bf16-faithful oracle (same op boundaries as MLX): tighter
+    xb, mb = x.cpu(), mods.cpu()
+    lnb = O.layer_norm(xb)
+    refb = torch.cat([(1 + mb[:, None, D:2 * D]) * lnb[:, :S] + mb[:, None, 0:D],
+                      (1 + mb[:, None, 3 * D:]) * lnb[:, S:] + mb[:, None, 2 * D:3 * D]], dim=1)
+    assert rel_l2(out, refb) < 2e-3
+
+
+# ------------------------------------------------------------------ qk norm + rope + V^T
+@pytest.mark.parametrize("T,S", [(96, 32), (77, 13)])
+def test_qk_norm_rope_vt(dev, T, S):
+    from flux_generator_amd import ops
+    B, H = 2, 3
+    D = H * 128
+    qkv = rnd(B, T, 3 * D, seed=1)
+    ws = [(1 + 0.2 * rnd(128, seed=10 + i).float()).to(BF) for i in range(4)]   # q_txt, k_txt, q_img, k_img
+    ids = torch.zeros(B, T, 3, dtype=torch.int32)
+    ids[:, S:, 1] = torch.arange(T - S, dtype=torch.int32) // 7
+    ids[:, S:, 2] = torch.arange(T - S, dtype=torch.int32) % 7
+    rope = ops.rope_table(ids.to(dev), [16, 56, 56], 10000.0)
+    Tpad = (T + 63) // 64 * 64
+    Q = torch.empty(B, H, T, 128, dtype=BF, device=dev)
+    K = torch.empty_like(Q)
+    Vt = torch.full((B, H, 128, Tpad), 7.0, dtype=BF, device=dev)
+    ops.qk_norm_rope(qkv, 3 * D, B, T, S, H, ws[0], ws[1], ws[2], ws[3], rope, T * 128, Q, K, Vt, Tpad)
+
+    f = qkv.float().cpu()
+    q, k, v = [O._split_heads(t, H) for t in torch.chunk(f, 3, dim=-1)]
+    pe = O.embed_nd(ids, [16, 56, 56], 10000).to(BF).float()
+
+    def norm(t, wt, wi):
+        return torch.cat([O.rms_norm(t[:, :, :S], wt.float().cpu()), O.rms_norm(t[:, :, S:], wi.float().cpu())], dim=2)
+
+    qr = O.apply_rope(norm(q, ws[0], ws[2]), pe)
+    kr = O.apply_rope(norm(k, ws[1], ws[3]), pe)
+    assert rel_l2(Q, qr) < TOL and rel_l2(K, kr) < TOL
+    assert torch.equal(Vt[..., :T].float().cpu(), v.transpose(-1, -2))        # pure data movement: exact
+    assert torch.count_nonzero(Vt[..., T:]) == 0                                # zero padding
+    # rope table itself (cos, sin) vs the oracle's rotation matrices, both rounded to bf16
+    assert rel_l2(rope[..., 0], pe[:, 0, :, :, 0, 0]) < 1e-3 and rel_l2(rope[..., 1], pe[:, 0, :, :, 1, 0]) < 1e-3
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,H,T", [(1, 2, 128), (2, 3, 200), (1, 1, 1280), (1, 2, 65)])
+def test_attention(dev, B, H, T):
+    from flux_generator_amd import ops
+    Tpad = (T + 63) // 64 * 64
+    q, k, v = rnd(B, H, T, 128, seed=1), rnd(B, H, T, 128, seed=2), rnd(B, H, T, 128, seed=3)
+    vt = torch.zeros(B, H, 128, Tpad, dtype=BF, device=dev)
+    vt[..., :T] = v.transpose(-1, -2)
+    o = torch.empty(B, T, H * 128, dtype=BF, device=dev)
+    ops.attention_d128(q, k, vt, o, H * 128, B, H, T, Tpad, 128 ** -0.5)
+    ref = O.sdpa(q.float().cpu(), k.float().cpu(), v.float().cpu(), 128 ** -0.5).transpose(1, 2).reshape(B, T, -1)
+    assert rel_l2(o, ref) < 6e-3      # P is rounded to bf16 before the PV product
+    # independent check of the oracle's sdpa itself
+    ind = torch.nn.functional.scaled_dot_product_attention(q.float().cpu(), k.float().cpu(), v.float().cpu())
+    assert rel_l2(ref, ind.transpose(1, 2).reshape(B, T, -1)) < 1e-5
+
+
+def test_attention_forced_rescale(dev):
+    """A key that spikes late forces the online-softmax rescale branch (rare on random data)."""
+    from flux_generator_amd import ops
+    B, H, T = 1, 1, 256
+    q, k, v = rnd(B, H, T, 128, seed=1), rnd(B, H, T, 128, seed=2, scale=0.1), rnd(B, H, T, 128, seed=3)
+    k[0, 0, 200] = q[0, 0, 17] * 2.0          # query 17 meets its spike in the 4th key tile
+    k[0, 0, 70] = q[0, 0, 140] * 1.5
+    vt = v.transpose(-1, -2).contiguous()
+    o = torch.empty(B, T, 128, dtype=BF, device=dev)
+    ops.attention_d128(q, k, vt, o, 128, B, H, T, T, 128 ** -0.5)
+    ref = O.sdpa(q.float().cpu(), k.float().cpu(), v.float().cpu(), 128 ** -0.5).transpose(1, 2).reshape(B, T, -1)
+    assert rel_l2(o, ref) < 6e-3
+    assert rel_l2(o[0, 17], ref[0, 17]) < 1e-2 and rel_l2(o[0, 140], ref[0, 140]) < 1e-2
+
+
+# ------------------------------------------------------------------ embeddings, sampler, pack
+def test_timestep_embedding(dev):
+    from flux_generator_amd import ops
+    t = torch.tensor([1.0, 0.75, 0.5, 0.25, 0.0, 0.3141], dtype=BF)
+    got = ops.timestep_embedding(t.to(dev), 256).float().cpu()
+    ref = O.timestep_embedding(t, 256).float()
+    # cos/sin of arguments up to 1000 rad, then bf16: allow one bf16 ulp on a handful of entries
+    assert (got - ref).abs().max() <= 2 ** -7
+    assert ((got - ref).abs() > 0).float().mean() < 0.05
+
+
+def test_euler_and_pack(dev):
+    from flux_generator_amd import ops
+    x, p = rnd(2, 96, 64, seed=1), rnd(2, 96, 64, seed=2)
+    for dt in (-0.5, -0.0117):
+        dtb = float(torch.tensor(dt, dtype=BF))
+        got = ops.euler_step(x, p, dtb)
+        ref = O.euler_step(p.cpu(), x.cpu(), 0.0, dt)          # bf16 oracle: identical op boundaries
+        assert torch.equal(got.cpu(), ref)
+    z = rnd(2, 12, 20, 16, seed=3)
+    packed = ops.pack_latents(z)
+    ref_p, ids = O.prepare_latent_images(z.cpu())
+    assert torch.equal(packed.cpu(), ref_p)                      # bit exact
+    assert torch.equal(ops.unpack_latents(packed, 12, 20).cpu(), z.cpu())
+    aff = ops.unpack_latents(packed, 12, 20, 0.3611, 0.1159)
+    assert rel_l2(aff, z.float().cpu() / 0.3611 + 0.1159) < TOL
