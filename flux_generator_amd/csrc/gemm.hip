@@ -10,34 +10,75 @@ struct TileCfg {
   void (*conv)(const GemmParams);
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
 constexpr TileCfg make_cfg() {
-  return TileCfg{BM, BN, WM * WN * 64, 2 * (BM + BN) * 64 * 2,
-                 gemm_nt_kernel<BM, BN, WM, WN, 0>, gemm_nt_kernel<BM, BN, WM, WN, 1>};
+  return TileCfg{BM, BN, WM * WN * 64, NSTAGE * (BM + BN) * 64 * 2,
+                 gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE>,
+                 gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE>};
 }
 
 // index 0 is unused ("auto")
 const TileCfg kCfgs[] = {
     TileCfg{0, 0, 0, 0, nullptr, nullptr},
-    make_cfg<128, 128, 2, 2>(),  // 1: default large tile, 64 KiB LDS, 2 blocks/CU
-    make_cfg<128, 64, 2, 2>(),   // 2: more blocks for N=3072 outputs at small M
-    make_cfg<64, 128, 2, 2>(),   // 3
-    make_cfg<64, 64, 2, 2>(),    // 4: tiny problems (N=64 final layer)
-    make_cfg<256, 128, 4, 2>(),  // 5: 8 waves, fewer LDS bytes per flop
-    make_cfg<128, 256, 2, 4>(),  // 6
+    make_cfg<128, 128, 2, 2, 2, 0>(),  // 1: 64 KiB LDS, 2 blocks/CU
+    make_cfg<128, 64, 2, 2, 2, 0>(),   // 2: more blocks for N=3072 outputs at small M
+    make_cfg<64, 128, 2, 2, 2, 0>(),   // 3
+    make_cfg<64, 64, 2, 2, 2, 0>(),    // 4: tiny problems (N=64 final layer)
+    make_cfg<256, 128, 4, 2, 2, 0>(),  // 5: 8 waves, 96 KiB
+    make_cfg<256, 256, 2, 4, 2, 0>(),  // 6: 8 waves x (128x64), 128 KiB
+    make_cfg<128, 128, 2, 2, 2, 1>(),  // 7: fragment-pipelined variants of 1,2,3,5,6
+    make_cfg<128, 64, 2, 2, 2, 1>(),   // 8
+    make_cfg<64, 128, 2, 2, 2, 1>(),   // 9
+    make_cfg<256, 128, 4, 2, 2, 1>(),  // 10
+    make_cfg<256, 256, 2, 4, 2, 1>(),  // 11
+    make_cfg<256, 128, 4, 2, 3, 1>(),  // 12: 3-deep ring, 144 KiB
+    make_cfg<128, 128, 2, 2, 3, 1>(),  // 13
+    make_cfg<128, 256, 2, 4, 2, 1>(),  // 14
+    make_cfg<256, 256, 4, 2, 2, 1>(),  // 15: 8 waves x (64x128)
+    make_cfg<128, 128, 2, 4, 3, 1>(),  // 16: 8 waves x (64x32), 3-deep ring
+    make_cfg<128, 128, 2, 2, 4, 1>(),  // 17: 4-deep ring, 128 KiB
+    make_cfg<256, 224, 4, 2, 2, 1>(),  // 18: 21504 = 96 x 224 -> 480 tiles at M = 1280
+    make_cfg<256, 192, 4, 2, 2, 1>(),  // 19: 9216 = 48 x 192 -> 240 tiles at M = 1280
+    make_cfg<128, 128, 4, 2, 3, 1>(),  // 20: 8 waves x (32x64), 3-deep ring
+    make_cfg<128, 192, 2, 2, 3, 1>(),  // 21: 4 waves x (64x96), 120 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 bool g_attr_set[kNumCfgs][2] = {};
 
-int pick_cfg(long long m_total, int N) {
-  // enough 128x128 tiles to give every CU >= 2 blocks -> big tile; otherwise shrink N-tile.
-  long long t128 = ((m_total + 127) / 128) * ((N + 127) / 128);
-  if (N <= 64) return 4;
-  if (t128 >= 512) return 1;
-  long long t12864 = ((m_total + 127) / 128) * ((N + 63) / 64);
-  if (t12864 >= 384) return 2;
-  return 4;
+// Tile selection = argmin of a two-term cost model over the compiled configurations:
+//   rounds(cfg)  = ceil(tiles / (256 CUs x co-resident blocks per CU))        (wave quantisation)
+//   t_tile(cfg)  = tile FLOPs x blocks/CU / chip-rate(cfg)                    (measured, MI355X)
+// chip-rate is the throughput each configuration reaches with every CU busy on cold (HBM-streamed)
+// weights, taken from tools/gemm_tune.py sweeps (profiles/gemm_tune_r01.txt).
+struct Cand { int cfg; int bpc; float rate_tf; };
+const Cand kCands[] = {
+    {15, 1, 1030.f},  // 256x256, 8 waves
+    {18, 1, 1080.f},  // 256x224
+    {19, 1, 1010.f},  // 256x192
+    {12, 1, 900.f},   // 256x128, 3-deep ring
+    {16, 1, 850.f},   // 128x128, 8 waves, 3-deep ring
+    {7, 2, 950.f},    // 128x128, 4 waves, 2 blocks/CU
+    {8, 2, 760.f},    // 128x64
+    {9, 2, 740.f},    // 64x128
+    {4, 4, 480.f},    // 64x64
+};
+
+int pick_cfg(const int* group_m, int ngroups, int nbatch, int N) {
+  float best = 3.4e38f;
+  int best_cfg = 4;
+  for (const Cand& c : kCands) {
+    const TileCfg& t = kCfgs[c.cfg];
+    long long tiles = 0;
+    for (int g = 0; g < ngroups; ++g) tiles += (long long)((group_m[g] + t.bm - 1) / t.bm) * nbatch;
+    tiles *= (N + t.bn - 1) / t.bn;
+    const long long slots = 256LL * c.bpc;
+    const long long rounds = (tiles + slots - 1) / slots;
+    // relative time: rounds x (tile area x blocks/CU / rate); K is common to all candidates
+    const float cost = (float)rounds * (float)(t.bm * t.bn) * (float)c.bpc / c.rate_tf;
+    if (cost < best) { best = cost; best_cfg = c.cfg; }
+  }
+  return best_cfg;
 }
 
 int launch(GemmParams& p, int cfg_idx, bool conv, hipStream_t s) {
@@ -106,16 +147,16 @@ extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.out_f32 = d->out_f32;
   if (p.out_f32 && d->epi != FLUXHIP_EPI_BIAS) return FLUXHIP_EINVAL;
-  int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(m_total, d->N);
+  const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
+  int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N);
   return launch(p, cfg, false, (hipStream_t)stream);
 }
 
 extern "C" int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d) {
   if (!d || d->ngroups < 1 || d->ngroups > 2) return FLUXHIP_EINVAL;
   if (d->tile_cfg > 0) return d->tile_cfg < kNumCfgs ? d->tile_cfg : FLUXHIP_EINVAL;
-  long long m_total = 0;
-  for (int g = 0; g < d->ngroups; ++g) m_total += (long long)d->g[g].M * d->nbatch;
-  return pick_cfg(m_total, d->N);
+  const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
+  return pick_cfg(gm, d->ngroups, d->nbatch, d->N);
 }
 
 extern "C" int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads) {
@@ -160,6 +201,6 @@ extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bia
   p.ldc = Cout;
   p.epi = epi;
   p.alpha = 1.f;
-  int cfg = pick_cfg(t.M, Cout);
+  int cfg = pick_cfg(&t.M, 1, 1, Cout);
   return launch(p, cfg, true, (hipStream_t)stream);
 }

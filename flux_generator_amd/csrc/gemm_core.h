@@ -77,7 +77,14 @@ struct GemmParams {
   int out_f32;           // EPI_BIAS only: C is float32 (logits of the single-head VAE attention)
 };
 
-template <int BM, int BN, int WM, int WN, int AMODE>
+template <int N>
+DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NSTAGE-deep LDS ring: the loads of K-step kt+NSTAGE-1 are issued right after the barrier that
+// opens step kt, so they have NSTAGE-1 compute phases to land; waits are COUNTED (vmcnt(N), never a
+// drain in steady state) and the barrier is a raw s_barrier, because __syncthreads() would drain
+// the in-flight LDS-DMA (cdna guide §5, "Pipelining across barriers").
+template <int BM, int BN, int WM, int WN, int AMODE, int NSTAGE, int PIPE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p) {
   constexpr int BK = 64;
   constexpr int NWAVES = WM * WN;
@@ -85,8 +92,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
-  constexpr int APW = BM / 8 / NWAVES, BPW = BN / 8 / NWAVES;
-  static_assert(APW >= 1 && BPW >= 1, "tile too small for wave count");
+  constexpr int APW = BM / 8 / NWAVES;
+  // B pieces need not divide evenly over the waves (BN = 192, 224): the surplus slots re-fetch the
+  // last piece (same bytes to the same LDS address), which keeps the per-wave vmcnt arithmetic uniform.
+  constexpr int BPIECES = BN / 8, BPW = (BPIECES + NWAVES - 1) / NWAVES;
+  static_assert(APW >= 1 && BM % (8 * NWAVES) == 0 && BN % 16 == 0, "tile / wave-count mismatch");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   }
 #pragma unroll
   for (int i = 0; i < BPW; ++i) {
-    int row = (wave + i * NWAVES) * 8 + lr;
+    int row = min(wave + i * NWAVES, BPIECES - 1) * 8 + lr;
     int n = min(n0 + row, N - 1);
     bsrc[i] = (const char*)(gW + (long long)n * K) + lc * 16;
   }
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     }
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
-      glds16(bsrc[i] + (long long)kt * (BK * 2), sb + (wave + i * NWAVES) * 1024);
+      glds16(bsrc[i] + (long long)kt * (BK * 2), sb + min(wave + i * NWAVES, BPIECES - 1) * 1024);
   };
 
   // ---- fragment read offsets (same XOR as the staging source swizzle) ---------
@@ -209,30 +219,97 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = K / BK;
-  stage(0, 0);
-  wait_vm0();
-  __syncthreads();
+  constexpr int G = APW + BPW;                       // LDS-DMA instructions per wave per K-step
+  static_assert((NSTAGE - 1) * G <= 63, "vmcnt field");
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
-    const char* sa = smem + cur * STAGE_BYTES + (wm * WTM) * 128;
-    const char* sb = smem + cur * STAGE_BYTES + A_BYTES + (wn * WTN) * 128;
+  auto load_frags = [&](bf16x8(&af)[MI], bf16x8(&wf)[NJ], int slot, int kk) {
+    const char* sa = smem + slot * STAGE_BYTES + (wm * WTM) * 128 + foff[kk];
+    const char* sb = smem + slot * STAGE_BYTES + A_BYTES + (wn * WTN) * 128 + foff[kk];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MI], wf[NJ];
+    for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 2048);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 2048 + foff[kk]);
+    for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(sb + j * 2048);
+  };
+  auto mma = [&](const bf16x8(&af)[MI], const bf16x8(&wf)[NJ]) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(sb + j * 2048 + foff[kk]);
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+  };
+
+  if constexpr (PIPE == 0) {
+    // simple ring: wait -> barrier -> refill the freed slot -> read fragments -> MFMA
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < nkt) stage(s, s);
+    int cur = 0, nxt = NSTAGE - 1;                   // ring slots of step kt and step kt+NSTAGE-1
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + NSTAGE - 2 < nkt) wait_vmcnt<(NSTAGE - 2) * G>();
+      else wait_vmcnt<0>();                          // tail: fewer steps in flight than the ring holds
+      __builtin_amdgcn_s_barrier();                  // step kt landed for every wave; slot nxt is free
+      if (kt + NSTAGE - 1 < nkt) stage(kt + NSTAGE - 1, nxt);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[MI], wf[NJ];
+        load_frags(af, wf, cur, kk);
+        mma(af, wf);
+      }
+      cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+      nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+    }
+  } else {
+    // fragment-double-buffered ring: every MFMA cluster runs with the NEXT cluster's ds_reads in
+    // flight; the barrier (and the wait for the next K-step's LDS-DMA) sits between the two
+    // clusters of a step, so LDS latency and barrier skew hide under 32..64 MFMAs.
+    // The fragment reads are inline asm with hand-counted lgkmcnt: hipcc's own bookkeeping drains
+    // lgkmcnt(0) at the loop head, which serialises [reads -> wait -> MFMAs] inside each wave.
+    constexpr int NF = MI + NJ;
+    static_assert(NF <= 15, "lgkmcnt field");
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_rd = lds0 + (wm * WTM) * 128;             // + slot*STAGE_BYTES + foff[kk]
+    const uint32_t b_rd = lds0 + A_BYTES + (wn * WTN) * 128;
+    auto read_frags = [&](bf16x8(&af)[MI], bf16x8(&wf)[NJ], int slot, int kk) {
+      const uint32_t aa = a_rd + slot * STAGE_BYTES + foff[kk];
+      const uint32_t bb = b_rd + slot * STAGE_BYTES + foff[kk];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[i]) : "v"(aa), "n"(i * 2048) : "memory");
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(bb), "n"(j * 2048) : "memory");
+    };
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+      if (s < nkt) stage(s, s);
+    if (nkt >= NSTAGE) wait_vmcnt<(NSTAGE - 1) * G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    bf16x8 a0[MI], w0[NJ], a1[MI], w1[NJ];
+    read_frags(a0, w0, 0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+      read_frags(a1, w1, cur, 1);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NF) : "memory");      // a0/w0 landed, a1/w1 in flight
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, w0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nkt) {
+        if (kt + NSTAGE - 1 < nkt) wait_vmcnt<(NSTAGE - 2) * G>();      // step kt+1 landed (mine)
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my reads of slot cur are done
+        __builtin_amdgcn_s_barrier();                                   // ... and everybody else's
+        if (kt + NSTAGE < nkt) stage(kt + NSTAGE, cur);                 // refill the slot just drained
+        read_frags(a0, w0, nxt, 0);
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, w1);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
-    wait_vm0();
-    __syncthreads();
   }
 
   // ---- epilogue: lane holds C[m][n4 .. n4+3] -----------------------------------

@@ -27,7 +27,7 @@ def rnd(*shape, scale=1.0, seed=0, dev="cuda"):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 256), (200, 136, 128), (1280, 3072, 512),
                                    (37, 64, 64), (1024, 64, 3072)])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", list(range(0, 22)))
 def test_gemm_bias(dev, M, N, K, cfg):
     from flux_generator_amd import ops
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)

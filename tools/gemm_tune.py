@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Time every compiled GEMM tile configuration on the Flux GEMM shapes (run on the GPU box).
+Random bf16 operands (never zeros: DVFS inflates zero-data numbers), HIP events on the launch stream."""
+import json
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from flux_generator_amd import ops, _lib
+
+dev = torch.device("cuda:0")
+BF = torch.bfloat16
+lib = _lib.load()
+ncfg = 0
+import ctypes
+bm, bn, th = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+while lib.fluxhip_gemm_tile_shape(ncfg + 1, bm, bn, th) == 0:
+    ncfg += 1
+
+M = int(os.environ.get("TUNE_M", "1280"))
+shapes = {  # name: (M, N, K, epi)
+    "qkv(2grp)": (M, 9216, 3072, 0),
+    "proj(2grp)": (M, 3072, 3072, 2),
+    "mlp0(2grp)": (M, 12288, 3072, 1),
+    "mlp2(2grp)": (M, 3072, 12288, 2),
+    "linear1": (M, 21504, 3072, 0),
+    "linear2": (M, 3072, 15360, 2),
+}
+only = sys.argv[1:]  # optional list of cfg ids
+cfgs = [int(c) for c in only] if only else list(range(1, ncfg + 1))
+res = {}
+for name, (m, n, k, epi) in shapes.items():
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(m, k, generator=g, device=dev).to(BF)
+    nrot = max(2, int(700e6 // (n * k * 2)) + 1)      # rotate weights so they stream from HBM (cold), as in situ
+    ws = [(torch.randn(n, k, generator=g, device=dev) * k ** -0.5).to(BF) for _ in range(nrot)]
+    w = ws[0]
+    b = torch.randn(n, generator=g, device=dev).to(BF)
+    r = torch.randn(m, n, generator=g, device=dev).to(BF)
+    gate = torch.randn(n, generator=g, device=dev).to(BF)
+    out = torch.empty(m, n, dtype=BF, device=dev)
+    ref = None
+    row = {}
+    for c in cfgs:
+        try:
+            kw = dict(epi=epi, out=out, tile_cfg=c)
+            if epi == 2:
+                kw.update(res=r, gate=gate)
+            ops.linear(x, w, b, **kw)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = out.float().clone()
+            else:
+                err = float((out.float() - ref).abs().max())
+                assert err < 0.1, (name, c, err)
+            for _ in range(3):
+                ops.linear(x, w, b, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_it = 20
+            e0.record()
+            for it in range(n_it):
+                ops.linear(x, ws[it % nrot], b, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n_it
+            row[c] = round(2.0 * m * n * k / (ms * 1e-3) / 1e12, 1)
+        except Exception as ex:  # noqa
+            row[c] = f"ERR {ex}"
+    res[name] = row
+    best = max((v, c) for c, v in row.items() if isinstance(v, float))
+    print(f"{name:12s} M={m} N={n} K={k}: " + " ".join(f"c{c}={v}" for c, v in row.items()) + f"  BEST c{best[1]}={best[0]}", flush=True)
+print(json.dumps(res))
