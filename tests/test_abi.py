@@ -1,0 +1,71 @@
+"""The C-ABI library loads and exports every symbol include/fluxhip.h declares (no compute calls:
+this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "fluxhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fluxhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from flux_generator_amd import _lib
+    assert _lib.LIB_PATH.exists(), "build with `python -c 'import __graft_entry__ as g; g.build()'`"
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fluxhip.h but not exported"
+    assert set(_lib.SIGNATURES) == set(names), "ctypes binding table and header disagree"
+
+
+def test_loader_checks_abi_and_arch():
+    from flux_generator_amd import _lib
+    lib = _lib.load()
+    assert lib.fluxhip_abi_version() == 1 and lib.fluxhip_arch() == b"gfx950"
+
+
+def test_gemm_desc_layout_matches_header():
+    """sizeof/offsets of the ctypes mirror = the C struct (LP64): 2 x 80-byte groups + 72 bytes."""
+    from flux_generator_amd._lib import GemmDesc, GemmGroup
+    assert ctypes.sizeof(GemmGroup) == 80 and GemmGroup.M.offset == 72
+    assert ctypes.sizeof(GemmDesc) == 232 and GemmDesc.C2.offset == 200 and GemmDesc.alpha.offset == 224
+
+
+def test_tile_picker_is_host_only():
+    """fluxhip_gemm_tile_cfg does no device work, so it can be exercised on CPU: Flux shapes at
+    T = 1280 pick the tiles the sweep in profiles/ found best."""
+    from flux_generator_amd import _lib, ops
+    lib = _lib.load()
+
+    def cfg(groups, N, K):
+        d = ops.make_gemm_desc([dict(A=1, W=1, C=1, M=m) for m in groups], 1, N, K, K, N)
+        return lib.fluxhip_gemm_tile_cfg(ctypes.byref(d))
+
+    bm, bn, th = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    for groups, N, K, want in (([1280], 21504, 3072, (256, 224)), ([256, 1024], 9216, 3072, (256, 192)),
+                               ([256, 1024], 12288, 3072, (256, 256)), ([1280], 3072, 15360, (128, 128))):
+        c = cfg(groups, N, K)
+        assert lib.fluxhip_gemm_tile_shape(c, bm, bn, th) == 0
+        assert (bm.value, bn.value) == want, (groups, N, K, c)
+
+
+def test_product_path_has_no_oracle_or_cpu_fallback():
+    """The package never imports the oracle, and its ops refuse CPU tensors."""
+    import subprocess, sys
+    pk = os.path.join(ROOT, "flux_generator_amd")
+    out = subprocess.run(["grep", "-rIl", "--include=*.py", "-E", r"^\s*(from|import)\s+oracle", pk],
+                         capture_output=True, text=True).stdout.strip()
+    assert out == "", f"product code imports the oracle: {out}"
+    import pytest, torch
+    from flux_generator_amd import ops
+    with pytest.raises(ops.FluxHipError):
+        ops.linear(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))
+    from flux_generator_amd.flux.model import Flux, FluxParams
+    with pytest.raises(ops.FluxHipError):
+        Flux(FluxParams(64, 64, 128, 256, 4.0, 2, 1, 1, [16, 56, 56], 10000, True, False), device="cpu")
