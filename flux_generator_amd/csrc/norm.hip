@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   const int p0 = chunk * ppb;
   const int p1 = min(p0 + ppb, HW);
   float s = 0.f, q = 0.f;
+#pragma unroll 4
   for (int p = p0 + prow; p < p1; p += pstep) {
     u32x4 w = *((const u32x4*)(x + ((long long)b * HW + p) * C) + cc);
 #pragma unroll
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(256) void gn_partial_cg4_kernel(const bf16_t* __res
   const int p0 = chunk * ppb;
   const int p1 = min(p0 + ppb, HW);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll 4
   for (int p = p0 + prow; p < p1; p += pstep) {
     u32x4 w = *((const u32x4*)(x + ((long long)b * HW + p) * C) + cc);
     float a0 = bf_lo(w[0]), a1 = bf_hi(w[0]), a2 = bf_lo(w[1]), a3 = bf_hi(w[1]);
@@ -273,18 +275,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x;
-  if (tid < G) {
-    float ts = 0.f, tq = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-      const float* o = ws + (((long long)b * nchunks + k) * G + tid) * 2;
-      ts += o[0];
-      tq += o[1];
-    }
-    const float cnt = (float)HW * (float)(C / G);
-    const float mean = ts / cnt;
-    const float var = fmaxf(tq / cnt - mean * mean, 0.f);
-    s_mean[tid] = mean;
-    s_rstd[tid] = rsqrtf(var + eps);
+  if (tid < G) {   // (mean, rstd) per group, reduced once by gn_finalize_kernel
+    const float* st = ws + ((long long)gridDim.y * nchunks * G + (long long)b * G + tid) * 2;
+    s_mean[tid] = st[0];
+    s_rstd[tid] = st[1];
   }
   __syncthreads();
   const int cpr = C >> 3;
@@ -302,21 +296,62 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   }
   const int p0 = chunk * ppb;
   const int p1 = min(p0 + ppb, HW);
-  for (int p = p0 + prow; p < p1; p += pstep) {
-    const long long off = ((long long)b * HW + p) * C;
-    u32x4 w = *((const u32x4*)(x + off) + cc);
-    u32x4 o;
+  // fold normalisation + affine into one fma per element: y = x * a + c
+  float fa[8], fc[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float y0 = (bf_lo(w[e]) - mu[2 * e]) * rs[2 * e] * bf_lo(gw[e]) + bf_lo(bw[e]);
-      float y1 = (bf_hi(w[e]) - mu[2 * e + 1]) * rs[2 * e + 1] * bf_hi(gw[e]) + bf_hi(bw[e]);
-      if (silu) {
-        y0 = silu_f(y0);
-        y1 = silu_f(y1);
-      }
-      o[e] = pack_bf16x2(y0, y1);
+  for (int e = 0; e < 4; ++e) {
+    fa[2 * e] = rs[2 * e] * bf_lo(gw[e]);
+    fa[2 * e + 1] = rs[2 * e + 1] * bf_hi(gw[e]);
+    fc[2 * e] = bf_lo(bw[e]) - mu[2 * e] * fa[2 * e];
+    fc[2 * e + 1] = bf_hi(bw[e]) - mu[2 * e + 1] * fa[2 * e + 1];
+  }
+  constexpr int U = 4;   // independent 16-B loads in flight per thread
+  for (int p = p0 + prow; p < p1; p += pstep * U) {
+    u32x4 w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pp = min(p + u * pstep, p1 - 1);
+      w[u] = *((const u32x4*)(x + ((long long)b * HW + pp) * C) + cc);
     }
-    *((u32x4*)(out + off) + cc) = o;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pp = p + u * pstep;
+      if (pp >= p1) break;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y0 = fmaf(bf_lo(w[u][e]), fa[2 * e], fc[2 * e]);
+        float y1 = fmaf(bf_hi(w[u][e]), fa[2 * e + 1], fc[2 * e + 1]);
+        if (silu) {
+          y0 = silu_f(y0);
+          y1 = silu_f(y1);
+        }
+        o[e] = pack_bf16x2(y0, y1);
+      }
+      *((u32x4*)(out + ((long long)b * HW + pp) * C) + cc) = o;
+    }
+  }
+}
+
+// one wave per (batch, group): deterministic (fixed-order) reduction of the per-chunk partials
+__global__ __launch_bounds__(64) void gn_finalize_kernel(float* __restrict__ ws, int B, int G,
+                                                         int nchunks, float cnt, float eps) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int b = i / G, g = i - b * G;
+  float ts = 0.f, tq = 0.f;
+  for (int k = lane; k < nchunks; k += 64) {
+    const float* o = ws + (((long long)b * nchunks + k) * G + g) * 2;
+    ts += o[0];
+    tq += o[1];
+  }
+  ts = wave_sum(ts);
+  tq = wave_sum(tq);
+  if (lane == 0) {
+    const float mean = ts / cnt;
+    const float var = fmaxf(tq / cnt - mean * mean, 0.f);
+    float* st = ws + ((long long)B * nchunks * G + i) * 2;
+    st[0] = mean;
+    st[1] = rsqrtf(var + eps);
   }
 }
 
@@ -380,7 +415,8 @@ extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, con
   int ppb = 1024;
   while (ppb > 32 && (long long)B * ((HW + ppb - 1) / ppb) < 512) ppb >>= 1;
   const int nchunks = (HW + ppb - 1) / ppb;
-  if (ws_bytes < (int64_t)B * nchunks * G * 2 * (int64_t)sizeof(float)) return FLUXHIP_EINVAL;
+  if (ws_bytes < ((int64_t)B * nchunks * G + (int64_t)B * G) * 2 * (int64_t)sizeof(float))
+    return FLUXHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(nchunks, B), block(256);
   if (cg == 4)
@@ -389,6 +425,8 @@ extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, con
   else
     hipLaunchKernelGGL(gn_partial_kernel, grid, block, 0, s, (const bf16_t*)x, (float*)ws, HW, C,
                        G, nchunks, ppb);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, s, (float*)ws, B, G, nchunks,
+                     (float)HW * (float)cg, eps);
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, (const bf16_t*)x, (const float*)ws,
                      (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)out, HW, C, G, nchunks,
                      eps, silu, ppb);

@@ -145,8 +145,28 @@ class FluxPipeline:
         yield from self._denoising_loop(x_T, x_ids, txt, txt_ids, vec, num_steps=num_steps, guidance=guidance)
 
     def decode(self, x: torch.Tensor, latent_size: Tuple[int, int] = (64, 64)) -> torch.Tensor:
-        """flux/flux.py:157-162: [b,L,64] -> [b,8h,8w,3] float in [0,1] (unpack, VAE decode, clip fused)."""
-        return self.ae.decode_packed(x, latent_size)
+        """flux/flux.py:157-162: [b,L,64] -> [b,8h,8w,3] float in [0,1] (unpack, VAE decode, clip fused).
+        With use_graph the ~150 launches of a decode are captured once per shape and replayed."""
+        if not self.use_graph:
+            return self.ae.decode_packed(x, latent_size)
+        key = ("decode", x.shape[0], tuple(latent_size))
+        ent = self._graphs.get(key)
+        if ent is None:
+            static_in = x.to(self.dtype).contiguous().clone()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.ae.decode_packed(static_in, latent_size)      # warm-up (attribute calls, workspaces)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = self.ae.decode_packed(static_in, latent_size)
+            ent = (g, static_in, static_out)
+            self._graphs[key] = ent
+        g, static_in, static_out = ent
+        static_in.copy_(x)
+        g.replay()
+        return static_out.clone()
 
     def generate_images(self, text: str, n_images: int = 1, num_steps: int = 35, guidance: float = 4.0,
                         latent_size: Tuple[int, int] = (64, 64), seed=None, reload_text_encoders: bool = True,

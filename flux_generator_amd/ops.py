@@ -223,7 +223,7 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     if out is None:
         out = torch.empty_like(x)
     ws = _gn_ws.get(x.device)
-    need = B * ((H * W_ + 31) // 32) * groups * 2 * 4
+    need = (B * ((H * W_ + 31) // 32) * groups + B * groups) * 2 * 4
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(max(need // 4, 1 << 18), dtype=torch.float32, device=x.device)
         _gn_ws[x.device] = ws

@@ -148,7 +148,7 @@ int fluxhip_unpack_latents_bf16(const void* x, void* out, int B, int h, int w, i
                                 float shift, void* stream);
 
 /* GroupNorm(G groups, eps, affine) [+ SiLU] on NHWC bf16 (nn.GroupNorm(pytorch_compatible=True),
- * flux/autoencoder.py:29-35,62-78,266).  ws: float workspace >= B*G*2*nchunks floats.
+ * flux/autoencoder.py:29-35,62-78,266).  ws: float workspace of >= (B*ceil(HW/32)*G + B*G)*2 floats.
  * Two launches (partial statistics, then normalise) on `stream`. */
 int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, const void* beta, void* out,
                                 int B, int HW, int C, int G, float eps, int silu, void* ws,
