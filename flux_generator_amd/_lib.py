@@ -19,7 +19,7 @@ class GemmGroup(C.Structure):
     _fields_ = [
         ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p),
         ("res", c_void_p), ("gate", c_void_p),
-        ("a_bstride", c_int64), ("c_bstride", c_int64), ("gate_bstride", c_int64),
+        ("a_bstride", c_int64), ("c_bstride", c_int64), ("gate_bstride", c_int64), ("w_bstride", c_int64),
         ("M", C.c_int32), ("_pad", C.c_int32),
     ]
 
@@ -45,7 +45,7 @@ SIGNATURES = {
     "fluxhip_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "fluxhip_gemm_tile_cfg": (c_int, [C.POINTER(GemmDesc)]),
     "fluxhip_gemm_tile_shape": (c_int, [c_int, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),
-    "fluxhip_conv2d_bf16": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p]),
+    "fluxhip_conv2d_bf16": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_void_p]),
     "fluxhip_conv2d_small": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "fluxhip_small_linear_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "fluxhip_ln_modulate_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64,
@@ -60,6 +60,13 @@ SIGNATURES = {
     "fluxhip_pack_latents_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fluxhip_unpack_latents_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "fluxhip_groupnorm_silu_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_void_p, c_int64, c_void_p]),
+    "fluxhip_attention_strided_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                               c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
+    "fluxhip_layernorm_affine_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p]),
+    "fluxhip_concat_channels_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "fluxhip_axpbypcz_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_float, c_float, c_float, c_void_p]),
+    "fluxhip_pixel_linear_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "fluxhip_sincos_embed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fluxhip_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
 }
 

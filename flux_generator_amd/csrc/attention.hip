@@ -1,78 +1,97 @@
-// Joint (txt+img) non-causal flash attention, head_dim 128, bf16 in / fp32 softmax / bf16 out.
-// Replaces mx.fast.scaled_dot_product_attention(q, k, v, scale=D**-0.5) and the
-// transpose/reshape after it (reference flux/layers.py:36-43; joint [txt;img] token order from
-// flux/layers.py:212-214).
+// Non-causal flash attention, head_dim 128 (Flux joint txt+img attention) or 64 (SD/SDXL UNet
+// self- and cross-attention), bf16 in / fp32 softmax / bf16 out.
+// Replaces mx.fast.scaled_dot_product_attention(q, k, v, scale=D**-0.5) and the transpose/reshape
+// after it (reference flux/layers.py:36-43; joint [txt;img] token order from flux/layers.py:212-214)
+// and nn.MultiHeadAttention's softmax(q k^T / sqrt(d)) v (stable_diffusion/.../unet.py:46-54,64-71).
 //
 // MI355X design (64-lane waves, v_mfma_f32_32x32x16_bf16):
 //  * one wave owns 32 query rows; NW waves per workgroup share the K / V^T tiles in LDS.
 //  * both products are computed TRANSPOSED so that every per-query quantity is lane-local:
 //        S^T[key][q] = K (A, from LDS) x Q^T (B, registers)        -> lane holds 16 keys of query (lane&31)
-//        O^T[d][q]   = V^T (A, from LDS) x P^T (B, registers)       -> lane holds 64 d's of query (lane&31)
+//        O^T[d][q]   = V^T (A, from LDS) x P^T (B, registers)       -> lane holds HD/2 d's of query (lane&31)
 //    the S^T accumulator layout *is* the B-operand layout of the second product (up to a fixed key
 //    permutation that is applied to the V^T fragment address instead), so P never leaves registers
 //    and the online-softmax rescale of O needs no cross-lane traffic; row max / row sum need one
 //    exchange with lane^32.
-//  * K tile [64 keys][128 d] and V^T tile [128 d][64 keys] arrive by LDS-DMA
-//    (global_load_lds_dwordx4), double-buffered, one barrier per KV tile. The LDS image is
-//    lane-linear, so the bank swizzle is applied to the per-lane *source* address and again on
-//    the fragment reads (K: 16-B chunk ^= row&15 -> conflict-free ds_read_b128;
-//    V^T: chunk ^= (row>>1)&7).
-//  * V^T ([B][H][128][Tpad], zero padded) is produced by fluxhip_qk_norm_rope_bf16.
+//  * K tile [64 keys][HD] and V^T tile [HD][64 keys] arrive by LDS-DMA (global_load_lds_dwordx4),
+//    double-buffered, one barrier per KV tile. The LDS image is lane-linear, so the bank swizzle is
+//    applied to the per-lane *source* address and again on the fragment reads
+//    (256-B rows: 16-B chunk ^= row&15; 128-B rows: chunk ^= (row>>1)&7 -> conflict-free b128 reads).
+//  * Q and K are addressed through (batch, head, row) strides, so both the head-major [B,H,T,HD]
+//    buffers of the Flux path and token-major [B,T,H*HD] projections of the UNet path are read in
+//    place; V^T ([B][H*HD][Tkpad], zero padded keys) comes from fluxhip_qk_norm_rope_bf16 (Flux) or
+//    directly from the value-projection GEMM written transposed (UNet).
 #include "../../include/fluxhip.h"
 #include "common.h"
 
 namespace {
 
-constexpr int KV = 64;                 // keys per tile
-constexpr int KT_BYTES = KV * 256;     // K tile
-constexpr int VT_BYTES = 128 * KV * 2; // V^T tile
-constexpr int STAGE = KT_BYTES + VT_BYTES;
+constexpr int KV = 64;  // keys per tile
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_d128_kernel(
-    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
-    bf16_t* __restrict__ O, int ldo, int H, int T, int Tpad, float scale_log2, int nqb) {
+struct AttnParams {
+  const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
+  long long q_bs, q_hs, q_rs;   // element strides: batch, head, row
+  long long k_bs, k_hs, k_rs;
+  int ldo, H, Tq, Tk, Tkpad, nqb;
+  float scale_log2;
+};
+
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
+  constexpr int RB = HD * 2;                  // bytes per K row
+  constexpr int CPR = RB / 16;                // 16-B chunks per K row
+  constexpr int KT_BYTES = KV * RB;           // K tile
+  constexpr int VT_BYTES = HD * KV * 2;       // V^T tile (HD rows of 128 B)
+  constexpr int STAGE = KT_BYTES + VT_BYTES;
+  constexpr int NDS = HD / 16;                // d-steps of S^T
+  constexpr int NDB = HD / 32;                // d-blocks of O^T
+  constexpr int KPW = KT_BYTES / 1024 / NW;   // K pieces per wave
+  constexpr int VPW = (HD / 8) / NW;          // V^T pieces per wave
+  constexpr int KROWS = 1024 / RB;            // K rows per 1-KiB piece
+
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, ql = lane & 31;
+  const int H = p.H, Tq = p.Tq, Tk = p.Tk, Tkpad = p.Tkpad;
 
   // XCD-aware map: all query blocks of one (b,h) land on the same XCD (they share K/V in its L2)
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int bh = logical / nqb;
-  const int qb = logical - bh * nqb;
+  const int bh = logical / p.nqb;
+  const int qb = logical - bh * p.nqb;
   const int b = bh / H, h = bh - b * H;
 
-  const bf16_t* Qh = Q + (long long)bh * T * 128;
-  const bf16_t* Kh = K + (long long)bh * T * 128;
-  const bf16_t* Vh = Vt + (long long)bh * 128 * Tpad;
+  const bf16_t* Qh = p.Q + b * p.q_bs + h * p.q_hs;
+  const bf16_t* Kh = p.K + b * p.k_bs + h * p.k_hs;
+  const bf16_t* Vh = p.Vt + (long long)bh * HD * Tkpad;
 
   const int q0 = qb * (NW * 32) + wave * 32;
-  const int qrow = min(q0 + ql, T - 1);
+  const int qrow = min(q0 + ql, Tq - 1);
 
   // Q^T fragments (B operand): lane (q = lane&31, hi) holds d = ds*16 + hi*8 .. +8
-  bf16x8 qf[8];
+  bf16x8 qf[NDS];
 #pragma unroll
-  for (int ds = 0; ds < 8; ++ds)
-    qf[ds] = *(const bf16x8*)(Qh + (long long)qrow * 128 + ds * 16 + hi * 8);
+  for (int ds = 0; ds < NDS; ++ds)
+    qf[ds] = *(const bf16x8*)(Qh + (long long)qrow * p.q_rs + ds * 16 + hi * 8);
 
   // staging sources
-  constexpr int KPW = 16 / NW;  // 1-KiB pieces per wave per tile (K: 16 pieces, V^T: 16 pieces)
-  const int kr = lane >> 4, kc = lane & 15;   // K piece: 4 rows x 16 chunks
-  const int vr = lane >> 3, vc = lane & 7;    // V^T piece: 8 rows x 8 chunks
-  const char* vsrc[KPW];
+  const int kr = lane / CPR, kc = lane % CPR;   // K piece: KROWS rows x CPR chunks
+  const int vr = lane >> 3, vc = lane & 7;      // V^T piece: 8 rows x 8 chunks
+  const char* vsrc[VPW];
   int krow[KPW], kchunk[KPW];
 #pragma unroll
   for (int i = 0; i < KPW; ++i) {
-    int piece = wave + i * NW;
-    int row = piece * 4 + kr;
+    int row = (wave + i * NW) * KROWS + kr;
     krow[i] = row;
-    kchunk[i] = kc ^ (row & 15);
-    int d = piece * 8 + vr;
+    kchunk[i] = kc ^ (HD == 128 ? (row & 15) : ((row >> 1) & 7));
+  }
+#pragma unroll
+  for (int i = 0; i < VPW; ++i) {
+    int d = (wave + i * NW) * 8 + vr;
     int lchunk = vc ^ ((d >> 1) & 7);
-    vsrc[i] = (const char*)(Vh + (long long)d * Tpad) + lchunk * 16;
+    vsrc[i] = (const char*)(Vh + (long long)d * Tkpad) + lchunk * 16;
   }
   auto stage = [&](int it, int buf) {
     char* sk = smem + buf * STAGE;
@@ -80,29 +99,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_d128_kernel(
     const int key0 = it * KV;
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-      int key = min(key0 + krow[i], T - 1);
-      glds16((const char*)(Kh + (long long)key * 128) + kchunk[i] * 16, sk + (wave + i * NW) * 1024);
+      int key = min(key0 + krow[i], Tk - 1);
+      glds16((const char*)(Kh + (long long)key * p.k_rs) + kchunk[i] * 16, sk + (wave + i * NW) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) glds16(vsrc[i] + (long long)key0 * 2, sv + (wave + i * NW) * 1024);
+    for (int i = 0; i < VPW; ++i) glds16(vsrc[i] + (long long)key0 * 2, sv + (wave + i * NW) * 1024);
   };
 
-  f32x16 oT[4];
+  f32x16 oT[NDB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NDB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
   // fragment read offsets
-  // K (A operand): row = kb*32 + ql, logical chunk = ds*2 + hi, phys = chunk ^ (row & 15)
-  const int k_rowoff = ql * 256;
-  const int k_sw = ql & 15;
-  // V^T (A operand): row d = dblk*32 + ql ; bytes: ((kb*4 + j*2 + {0,1}) ^ ((d>>1)&7))*16 + hi*8
+  // K (A operand): row = kb*32 + ql, logical chunk = ds*2 + hi, phys = chunk ^ swz(row)
+  const int k_rowoff = ql * RB;
+  const int k_sw = (HD == 128) ? (ql & 15) : ((ql >> 1) & 7);
+  // V^T (A operand): row d = db*32 + ql ; bytes: ((kb*4 + j*2 + {0,1}) ^ ((d>>1)&7))*16 + hi*8
   const int v_rowoff = ql * 128 + hi * 8;
-  const int v_sw = (ql >> 1) & 7;   // (dblk*32 + ql) >> 1 & 7 == (ql>>1)&7 since 32/2 = 16 = 0 mod 8
+  const int v_sw = (ql >> 1) & 7;
 
-  const int ntiles = (T + KV - 1) / KV;
+  const int ntiles = (Tk + KV - 1) / KV;
+  const float scale_log2 = p.scale_log2;
   stage(0, 0);
   wait_vm0();
   __syncthreads();
@@ -120,20 +140,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_d128_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) sT[kb][r] = 0.f;
 #pragma unroll
-      for (int ds = 0; ds < 8; ++ds) {
-        bf16x8 kf = *(const bf16x8*)(sk + kb * 32 * 256 + k_rowoff + (((ds * 2 + hi) ^ k_sw) << 4));
+      for (int ds = 0; ds < NDS; ++ds) {
+        bf16x8 kf = *(const bf16x8*)(sk + kb * 32 * RB + k_rowoff + (((ds * 2 + hi) ^ k_sw) << 4));
         sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sT[kb], 0, 0, 0);
       }
     }
     // ---- mask the key tail (last tile only) ----------------------------------
     const int key0 = it * KV;
-    if (key0 + KV > T) {
+    if (key0 + KV > Tk) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= T) sT[kb][r] = -1e30f;
+          if (key >= Tk) sT[kb][r] = -1e30f;
         }
     }
     // ---- online softmax (per query = per lane pair (l, l^32)) -----------------
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_d128_kernel(
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);
       l_run *= alpha;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NDB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
       m_run = m_new;
@@ -159,9 +179,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_d128_kernel(
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(fmaf(sT[kb][r], scale_log2, mneg));
-        sT[kb][r] = p;
-        psum += p;
+        float pv = __builtin_amdgcn_exp2f(fmaf(sT[kb][r], scale_log2, mneg));
+        sT[kb][r] = pv;
+        psum += pv;
       }
     l_run += psum;
 
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_d128_kernel(
           pf.u[e] = pack_bf16x2(sT[kb][8 * j + 2 * e], sT[kb][8 * j + 2 * e + 1]);
         const int c1 = kb * 4 + j * 2;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+        for (int db = 0; db < NDB; ++db) {
           const char* base = sv + db * 32 * 128 + v_rowoff;
           union { bf16x8 v; u32x2 h[2]; } vf;
           vf.h[0] = *(const u32x2*)(base + (((c1) ^ v_sw) << 4));
@@ -194,10 +214,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_d128_kernel(
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   const int q = q0 + ql;
-  if (q < T) {
-    bf16_t* orow = O + ((long long)b * T + q) * ldo + h * 128;
+  if (q < Tq) {
+    bf16_t* orow = p.O + ((long long)b * Tq + q) * p.ldo + h * HD;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int d0 = db * 32 + 8 * rg + 4 * hi;
@@ -209,7 +229,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_d128_kernel(
   }
 }
 
-bool g_attr_done = false;
+bool g_attr_done[2] = {false, false};
+
+template <int HD>
+int launch_attn(const AttnParams& p, int B, hipStream_t s) {
+  constexpr int NW = 4;
+  constexpr int lds = 2 * (KV * HD * 2 + HD * KV * 2);
+  auto fn = attn_kernel<HD, NW>;
+  bool& done = g_attr_done[HD == 128 ? 0 : 1];
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return FLUXHIP_ELAUNCH;
+    done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(B * p.H * p.nqb), dim3(NW * 64), lds, s, p);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
 
 }  // namespace
 
@@ -218,19 +253,34 @@ extern "C" int fluxhip_attention_d128_bf16(const void* Q, const void* K, const v
                                            void* stream) {
   if (!Q || !K || !Vt || !O || B < 1 || H < 1 || T < 1 || Tpad % 64 || Tpad < T || ldo % 4)
     return FLUXHIP_EINVAL;
-  constexpr int NW = 4;
-  const int nqb = (T + NW * 32 - 1) / (NW * 32);
-  const int lds = 2 * STAGE;
-  auto fn = attn_d128_kernel<NW>;
-  if (!g_attr_done) {
-    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return FLUXHIP_ELAUNCH;
-    g_attr_done = true;
-  }
-  const float scale_log2 = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(fn, dim3(B * H * nqb), dim3(NW * 64), lds, (hipStream_t)stream,
-                     (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, T,
-                     Tpad, scale_log2, nqb);
-  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+  AttnParams p{};
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.q_rs = p.k_rs = 128;
+  p.q_hs = p.k_hs = (long long)T * 128;
+  p.q_bs = p.k_bs = (long long)H * T * 128;
+  p.ldo = ldo; p.H = H; p.Tq = T; p.Tk = T; p.Tkpad = Tpad;
+  p.nqb = (T + 127) / 128;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  return launch_attn<128>(p, B, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                              const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                              const void* Vt, void* O, int ldo, int B, int H,
+                                              int head_dim, int Tq, int Tk, int Tkpad, float scale,
+                                              void* stream) {
+  if (!Q || !K || !Vt || !O || B < 1 || H < 1 || Tq < 1 || Tk < 1 || Tkpad % 64 || Tkpad < Tk)
+    return FLUXHIP_EINVAL;
+  if ((head_dim != 64 && head_dim != 128) || ldo % 4 || q_rs % 8 || k_rs % 8 || q_hs % 8 || k_hs % 8 ||
+      q_bs % 8 || k_bs % 8)
+    return FLUXHIP_EINVAL;
+  AttnParams p{};
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
+  p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
+  p.ldo = ldo; p.H = H; p.Tq = Tq; p.Tk = Tk; p.Tkpad = Tkpad;
+  p.nqb = (Tq + 127) / 128;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  return head_dim == 128 ? launch_attn<128>(p, B, (hipStream_t)stream)
+                         : launch_attn<64>(p, B, (hipStream_t)stream);
 }

@@ -198,6 +198,63 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(
   }
 }
 
+// Coalesced variant for wide inputs / very few outputs (conv_out 128 -> 3): LPP = Cin/8 lanes share
+// one output pixel, lane c owns the 16-byte channel chunk c of every tap, so each tap is one fully
+// coalesced Cin*2-byte row read; partial dot products are combined with xor-shuffles inside the lane
+// group.  The weights (Cout*9*Cin bf16, a few KB) stay in L1.
+template <int LPP, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_fewout_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+    void* __restrict__ out, int B, int H, int W, int Cout, int out_f32, int clip01) {
+  constexpr int Cin = LPP * 8;
+  const int tid = threadIdx.x;
+  const int c = tid % LPP;
+  const long long pix = (long long)blockIdx.x * (256 / LPP) + tid / LPP;
+  const long long npix = (long long)B * H * W;
+  const long long pp = pix < npix ? pix : npix - 1;
+  const int xx = (int)(pp % W);
+  const int yy = (int)((pp / W) % H);
+  const int b = (int)(pp / ((long long)W * H));
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int y = yy + ky - 1, xq = xx + kx - 1;
+      const bool ok = (y >= 0) & (y < H) & (xq >= 0) & (xq < W);
+      u32x4 xv = u32x4{0, 0, 0, 0};
+      if (ok) xv = *((const u32x4*)(x + (((long long)b * H + y) * W + xq) * Cin) + c);
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) {
+        const int co = min(o, Cout - 1);
+        u32x4 wv = *((const u32x4*)(w + (((long long)co * 3 + ky) * 3 + kx) * Cin) + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[o] += bf_lo(xv[e]) * bf_lo(wv[e]);
+          acc[o] += bf_hi(xv[e]) * bf_hi(wv[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < COUT; ++o)
+#pragma unroll
+    for (int s = LPP >> 1; s > 0; s >>= 1) acc[o] += __shfl_xor(acc[o], s, 64);
+  if (c == 0 && pix < npix) {
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      if (o >= Cout) break;
+      float v = acc[o] + (bias ? bf2f(bias[o]) : 0.f);
+      if (clip01) v = fminf(fmaxf(v + 1.f, 0.f), 2.f) * 0.5f;
+      const long long oi = pix * Cout + o;
+      if (out_f32) ((float*)out)[oi] = v;
+      else ((bf16_t*)out)[oi] = f2bf(v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int fluxhip_euler_step_bf16(const void* x, const void* pred, void* out, int64_t n,
@@ -244,7 +301,19 @@ extern "C" int fluxhip_conv2d_small(const void* x, const void* w, const void* bi
                                     void* stream) {
   if (!x || !w || !out || B < 1 || H < 1 || W < 1 || Cin % 8 || Cout < 1) return FLUXHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (Cout <= 4) {
+  if (Cout <= 4 && (Cin == 128 || Cin == 256 || Cin == 512 || Cin == 64)) {
+    const long long npix = (long long)B * H * W;
+#define FEWOUT(LPP)                                                                                \
+  hipLaunchKernelGGL((conv3x3_fewout_kernel<LPP, 4>),                                              \
+                     dim3((unsigned)((npix + (256 / LPP) - 1) / (256 / LPP))), dim3(256), 0, s,    \
+                     (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)bias, out, B, H, W, Cout,  \
+                     out_f32, clip01)
+    if (Cin == 64) FEWOUT(8);
+    else if (Cin == 128) FEWOUT(16);
+    else if (Cin == 256) FEWOUT(32);
+    else FEWOUT(64);
+#undef FEWOUT
+  } else if (Cout <= 4) {
     long long total = (long long)B * H * W;
     hipLaunchKernelGGL((conv3x3_small_kernel<4>), dim3((unsigned)((total + 255) / 256)), dim3(256),
                        0, s, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)bias, out, B, H, W,

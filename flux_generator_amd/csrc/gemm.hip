@@ -115,7 +115,7 @@ extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
   for (int g = 0; g < d->ngroups; ++g) {
     const fluxhip_gemm_group& s = d->g[g];
     if (!s.A || !s.W || !s.C || s.M <= 0) return FLUXHIP_EINVAL;
-    if (d->epi == FLUXHIP_EPI_GATE_RES && !s.res) return FLUXHIP_EINVAL;
+    if ((d->epi == FLUXHIP_EPI_GATE_RES || d->epi == FLUXHIP_EPI_GEGLU) && !s.res) return FLUXHIP_EINVAL;
     GemmGroup& t = p.g[g];
     t.A = (const bf16_t*)s.A;
     t.W = (const bf16_t*)s.W;
@@ -126,6 +126,7 @@ extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
     t.a_bstride = s.a_bstride;
     t.c_bstride = s.c_bstride;
     t.gate_bstride = s.gate_bstride;
+    t.w_bstride = s.w_bstride;
     t.M = s.M;
     m_total += (long long)s.M * d->nbatch;
   }
@@ -168,9 +169,9 @@ extern "C" int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads) 
 }
 
 extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bias, const void* res,
-                                   void* out, int B, int Hs, int Ws, int Cin, int Cout, int ksize,
-                                   int stride, int pad, int ups, int epi, const void* zero16,
-                                   void* stream) {
+                                   const void* addvec, void* out, int B, int Hs, int Ws, int Cin,
+                                   int Cout, int ksize, int stride, int pad, int ups, int epi,
+                                   const void* zero16, void* stream) {
   if (!x || !w || !out || !zero16) return FLUXHIP_EINVAL;
   if (Cin % 64 || Cout % 4 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
     return FLUXHIP_EINVAL;
@@ -201,6 +202,9 @@ extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bia
   p.ldc = Cout;
   p.epi = epi;
   p.alpha = 1.f;
+  p.addvec = (const bf16_t*)addvec;
+  p.addvec_rows = Ho * Wo;
+  p.addvec_stride = Cout;
   int cfg = pick_cfg(&t.M, 1, 1, Cout);
   return launch(p, cfg, true, (hipStream_t)stream);
 }

@@ -30,7 +30,7 @@ enum GemmEpi : int {
   EPI_SPLIT_GELU = 3, // n <  n_split: C  = acc + bias
                       // n >= n_split: C2[:, n - n_split + c2_coloff] = gelu_tanh(acc + bias)
   EPI_SILU = 4,       // C = silu(acc + bias)
-  EPI_GEGLU = 5,      // reserved (UNet)
+  EPI_GEGLU = 5,      // C = res * gelu_erf(acc + bias)       (UNet GEGLU: linear1(y) * gelu(linear2(y)))
 };
 
 struct GemmGroup {
@@ -43,6 +43,7 @@ struct GemmGroup {
   long long a_bstride; // elements between batches of A
   long long c_bstride; // elements between batches of C / res
   long long gate_bstride;
+  long long w_bstride; // elements between batches of W (0: shared weight)
   int M;               // rows per batch
   int tiles_m;         // ceil(M / BM)
 };
@@ -75,6 +76,9 @@ struct GemmParams {
   int tiles_m_total, tiles_n;
   float alpha;           // scales acc before bias (attention logits etc.)
   int out_f32;           // EPI_BIAS only: C is float32 (logits of the single-head VAE attention)
+  const bf16_t* addvec;  // optional [.., addvec_stride] vector added per group of addvec_rows output rows
+  int addvec_rows;
+  long long addvec_stride;
 };
 
 template <int N>
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   const long long a_bs = g1 ? p.g[1].a_bstride : p.g[0].a_bstride;
   const long long c_bs = g1 ? p.g[1].c_bstride : p.g[0].c_bstride;
   const long long gate_bs = g1 ? p.g[1].gate_bstride : p.g[0].gate_bstride;
+  const long long w_bs = g1 ? p.g[1].w_bstride : p.g[0].w_bstride;
   const int Mg = g1 ? p.g[1].M : p.g[0].M;
   const int tpb = g1 ? p.g[1].tiles_m : p.g[0].tiles_m;
   const int b = tm / tpb;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   for (int i = 0; i < BPW; ++i) {
     int row = min(wave + i * NWAVES, BPIECES - 1) * 8 + lr;
     int n = min(n0 + row, N - 1);
-    bsrc[i] = (const char*)(gW + (long long)n * K) + lc * 16;
+    bsrc[i] = (const char*)(gW + (long long)b * w_bs + (long long)n * K) + lc * 16;
   }
 
   // conv geometry decode (per staged row), hoisted out of the K loop
@@ -340,6 +345,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
       }
+      if (p.addvec) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
+        u32x2 aw = *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
+        v[0] = rbf(v[0]) + bf_lo(aw[0]);
+        v[1] = rbf(v[1]) + bf_hi(aw[0]);
+        v[2] = rbf(v[2]) + bf_lo(aw[1]);
+        v[3] = rbf(v[3]) + bf_hi(aw[1]);
+      }
       if (p.out_f32) {
         float* fdst = (float*)gC + (long long)b * c_bs + (long long)m * p.ldc + n4;
         *(f32x4*)fdst = f32x4{v[0], v[1], v[2], v[3]};
@@ -365,6 +377,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = rr[r] + rbf(v[r]);
         }
+      } else if (epi == EPI_GEGLU) {   // out = res * gelu_erf(acc + bias)   (y_a * nn.gelu(y_b))
+        const bf16_t* rp = gRes + (long long)b * c_bs + (long long)m * p.ldc + n4;
+        u32x2 rw = *(const u32x2*)rp;
+        v[0] = bf_lo(rw[0]) * rbf(gelu_erf_f(rbf(v[0])));
+        v[1] = bf_hi(rw[0]) * rbf(gelu_erf_f(rbf(v[1])));
+        v[2] = bf_lo(rw[1]) * rbf(gelu_erf_f(rbf(v[2])));
+        v[3] = bf_hi(rw[1]) * rbf(gelu_erf_f(rbf(v[3])));
       } else if (epi == EPI_SPLIT_GELU) {
         if (n4 >= p.n_split) {
 #pragma unroll

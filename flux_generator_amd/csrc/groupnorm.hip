@@ -1,0 +1,185 @@
+// GroupNorm (+SiLU) on NHWC bf16 — nn.GroupNorm(G, C, eps, affine, pytorch_compatible=True):
+// G groups of C/G contiguous channels, statistics over H*W*(C/G), biased variance, fp32 statistics.
+// Reference call sites: flux/autoencoder.py:29-35,62-78,266 (eps 1e-6) and
+// stable_diffusion/.../unet.py:98,139,145,391, vae.py:19,137,204 (eps 1e-5, C/G = 10,20,30,40,...).
+//
+// HBM-bound, three launches, deterministic (no atomics):
+//   1. gn_partial : per (batch, pixel chunk) PER-CHANNEL (sum, sumsq) -> ws[b][chunk][C][2]
+//                   (per-channel partials make any C/G work, incl. groups that straddle 16-B chunks)
+//   2. gn_finalize: one wave per (batch, group): fixed-order reduction -> (mean, rstd)
+//   3. gn_apply   : y = x*a + c per element (a, c fold mean/rstd/gamma/beta), optional SiLU
+// Threads own a fixed 16-byte channel chunk and stride over pixels with 4 loads in flight.
+#include "../../include/fluxhip.h"
+#include "common.h"
+
+namespace {
+
+// CB = channel chunks (of 8 channels) handled per block along blockIdx.z; 256 % CB == 0
+template <int CB>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x,
+                                                         float* __restrict__ ws, int HW, int C,
+                                                         int nchunks, int ppb) {
+  constexpr int ROWS = 256 / CB;
+  __shared__ float red[256][17];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int cc = blockIdx.z * CB + (tid % CB);   // 16-B channel chunk owned by this thread
+  const int prow = tid / CB;
+  const int p0 = chunk * ppb;
+  const int p1 = min(p0 + ppb, HW);
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  constexpr int U = 4;
+  for (int p = p0 + prow; p < p1; p += ROWS * U) {
+    u32x4 w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pp = p + u * ROWS;
+      w[u] = pp < p1 ? *((const u32x4*)(x + ((long long)b * HW + pp) * C) + cc) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = bf_lo(w[u][e]), c = bf_hi(w[u][e]);
+        s[2 * e] += a; q[2 * e] += a * a;
+        s[2 * e + 1] += c; q[2 * e + 1] += c * c;
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[tid][e] = s[e];
+    red[tid][8 + e] = q[e];
+  }
+  __syncthreads();
+  // CB*16 (channel, stat) pairs, each summed over ROWS pixel rows in a fixed order
+  for (int i = tid; i < CB * 16; i += 256) {
+    const int c8 = i >> 4, k = i & 15;
+    float t = 0.f;
+    for (int r = 0; r < ROWS; ++r) t += red[r * CB + c8][k];
+    const int ch = (blockIdx.z * CB + c8) * 8 + (k & 7);
+    ws[((((long long)b * nchunks + chunk) * C) + ch) * 2 + (k >> 3)] = t;
+  }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(float* __restrict__ ws, int B, int C, int G,
+                                                         int nchunks, float cnt, float eps) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int b = i / G, g = i - b * G;
+  const int cg = C / G;
+  float ts = 0.f, tq = 0.f;
+  const int items = nchunks * cg;
+  for (int k = lane; k < items; k += 64) {
+    const int chunk = k / cg, c = g * cg + (k - chunk * cg);
+    const float* o = ws + (((long long)b * nchunks + chunk) * C + c) * 2;
+    ts += o[0];
+    tq += o[1];
+  }
+  ts = wave_sum(ts);
+  tq = wave_sum(tq);
+  if (lane == 0) {
+    const float mean = ts / cnt;
+    const float var = fmaxf(tq / cnt - mean * mean, 0.f);
+    float* st = ws + ((long long)B * nchunks * C + i) * 2;
+    st[0] = mean;
+    st[1] = rsqrtf(var + eps);
+  }
+}
+
+template <int CB>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x,
+                                                       const float* __restrict__ ws,
+                                                       const bf16_t* __restrict__ gamma,
+                                                       const bf16_t* __restrict__ beta,
+                                                       bf16_t* __restrict__ out, int HW, int C, int G,
+                                                       int nchunks, int silu, int ppb) {
+  constexpr int ROWS = 256 / CB;
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid < G) {
+    const float* st = ws + ((long long)gridDim.y * nchunks * C + (long long)b * G + tid) * 2;
+    s_mean[tid] = st[0];
+    s_rstd[tid] = st[1];
+  }
+  __syncthreads();
+  const int cc = blockIdx.z * CB + (tid % CB);
+  const int prow = tid / CB;
+  const int cg = C / G;
+  u32x4 gw = *((const u32x4*)gamma + cc);
+  u32x4 bw = *((const u32x4*)beta + cc);
+  float fa[8], fc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = (cc * 8 + e) / cg;
+    const float ga = (e & 1) ? bf_hi(gw[e >> 1]) : bf_lo(gw[e >> 1]);
+    const float be = (e & 1) ? bf_hi(bw[e >> 1]) : bf_lo(bw[e >> 1]);
+    fa[e] = s_rstd[g] * ga;
+    fc[e] = be - s_mean[g] * fa[e];
+  }
+  const int p0 = chunk * ppb;
+  const int p1 = min(p0 + ppb, HW);
+  constexpr int U = 4;
+  for (int p = p0 + prow; p < p1; p += ROWS * U) {
+    u32x4 w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pp = min(p + u * ROWS, p1 - 1);
+      w[u] = *((const u32x4*)(x + ((long long)b * HW + pp) * C) + cc);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pp = p + u * ROWS;
+      if (pp >= p1) break;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y0 = fmaf(bf_lo(w[u][e]), fa[2 * e], fc[2 * e]);
+        float y1 = fmaf(bf_hi(w[u][e]), fa[2 * e + 1], fc[2 * e + 1]);
+        if (silu) {
+          y0 = silu_f(y0);
+          y1 = silu_f(y1);
+        }
+        o[e] = pack_bf16x2(y0, y1);
+      }
+      *((u32x4*)(out + ((long long)b * HW + pp) * C) + cc) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, const void* beta,
+                                           void* out, int B, int HW, int C, int G, float eps,
+                                           int silu, void* ws, int64_t ws_bytes, void* stream) {
+  if (!x || !gamma || !beta || !out || !ws) return FLUXHIP_EINVAL;
+  if (B < 1 || HW < 1 || C % 8 || G < 1 || G > 64 || C % G) return FLUXHIP_EINVAL;
+  const int cpr = C / 8;
+  const int cb = cpr % 64 == 0 ? 64 : cpr % 32 == 0 ? 32 : cpr % 16 == 0 ? 16 : cpr % 8 == 0 ? 8 : 0;
+  if (!cb) return FLUXHIP_EINVAL;   // C must be a multiple of 64
+  // pixels per block: aim for >= 512 blocks, keep the partial table small
+  int ppb = 1024;
+  while (ppb > 32 && (long long)B * ((HW + ppb - 1) / ppb) * (cpr / cb) < 512) ppb >>= 1;
+  const int nchunks = (HW + ppb - 1) / ppb;
+  if (ws_bytes < ((int64_t)B * nchunks * C + (int64_t)B * G) * 2 * (int64_t)sizeof(float))
+    return FLUXHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(nchunks, B, cpr / cb), block(256);
+#define GN_RUN(CB)                                                                                   \
+  do {                                                                                               \
+    hipLaunchKernelGGL((gn_partial_kernel<CB>), grid, block, 0, s, (const bf16_t*)x, (float*)ws, HW, \
+                       C, nchunks, ppb);                                                             \
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, s, (float*)ws, B, C, G,         \
+                       nchunks, (float)HW * (float)(C / G), eps);                                    \
+    hipLaunchKernelGGL((gn_apply_kernel<CB>), grid, block, 0, s, (const bf16_t*)x, (const float*)ws, \
+                       (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)out, HW, C, G, nchunks,   \
+                       silu, ppb);                                                                   \
+  } while (0)
+  if (cb == 64) GN_RUN(64);
+  else if (cb == 32) GN_RUN(32);
+  else if (cb == 16) GN_RUN(16);
+  else GN_RUN(8);
+#undef GN_RUN
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}

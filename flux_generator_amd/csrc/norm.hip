@@ -1,5 +1,5 @@
-// Memory-bound normalisation kernels of the denoise path (HBM roofline, wave-shuffle reductions,
-// 16-byte bf16 vector loads; no LDS except for the V transpose tile).
+// Memory-bound normalisation kernels of the Flux denoise path (HBM roofline, wave-shuffle reductions,
+// 16-byte bf16 vector loads; no LDS except for the V transpose tile). GroupNorm lives in groupnorm.hip.
 #include "../../include/fluxhip.h"
 #include "common.h"
 
@@ -174,187 +174,6 @@ __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// GroupNorm (+SiLU) on NHWC bf16 (nn.GroupNorm(pytorch_compatible=True): G groups of C/G
-// contiguous channels, statistics over H*W*(C/G), biased variance).
-// Pass 1: per (batch, pixel-chunk) partial sums per group  -> ws[b][chunk][G][2]  (deterministic)
-// Pass 2: reduce the partials, normalise, affine, optional SiLU.
-// ---------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x,
-                                                         float* __restrict__ ws, int HW, int C,
-                                                         int G, int nchunks, int ppb) {
-  // block = (chunk, b); thread t handles 16-byte channel chunk (t % (C/8)) over a strided pixel set
-  __shared__ float red[256 * 2];
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int cpr = C >> 3;                       // 16-B chunks per pixel
-  const int tid = threadIdx.x;
-  const int cc = tid % cpr;                     // channel chunk owned (fixed -> fixed group)
-  const int prow = tid / cpr, pstep = 256 / cpr;  // requires cpr | 256
-  const int p0 = chunk * ppb;
-  const int p1 = min(p0 + ppb, HW);
-  float s = 0.f, q = 0.f;
-#pragma unroll 4
-  for (int p = p0 + prow; p < p1; p += pstep) {
-    u32x4 w = *((const u32x4*)(x + ((long long)b * HW + p) * C) + cc);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = bf_lo(w[e]), c = bf_hi(w[e]);
-      s += a + c;
-      q += a * a + c * c;
-    }
-  }
-  red[tid] = s;
-  red[256 + tid] = q;
-  __syncthreads();
-  // group g covers channel chunks [g*cpg8, (g+1)*cpg8) where cpg8 = (C/G)/8 (>= 1 when C/G >= 8);
-  // when C/G < 8 one 16-B chunk spans several groups: handled by the fine path below.
-  const int cg = C / G;
-  if (cg >= 8) {
-    const int cpg8 = cg >> 3;
-    if (tid < G) {
-      float ts = 0.f, tq = 0.f;
-      for (int r = 0; r < pstep; ++r)
-        for (int k = 0; k < cpg8; ++k) {
-          int idx = r * cpr + tid * cpg8 + k;
-          ts += red[idx];
-          tq += red[256 + idx];
-        }
-      float* o = ws + (((long long)b * nchunks + chunk) * G + tid) * 2;
-      o[0] = ts;
-      o[1] = tq;
-    }
-  }
-}
-
-// fine path for C/G == 4 (C=128, G=32): per-thread chunk holds two groups
-__global__ __launch_bounds__(256) void gn_partial_cg4_kernel(const bf16_t* __restrict__ x,
-                                                             float* __restrict__ ws, int HW, int C,
-                                                             int G, int nchunks, int ppb) {
-  __shared__ float red[256 * 4];
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int cpr = C >> 3;
-  const int tid = threadIdx.x;
-  const int cc = tid % cpr;
-  const int prow = tid / cpr, pstep = 256 / cpr;
-  const int p0 = chunk * ppb;
-  const int p1 = min(p0 + ppb, HW);
-  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-#pragma unroll 4
-  for (int p = p0 + prow; p < p1; p += pstep) {
-    u32x4 w = *((const u32x4*)(x + ((long long)b * HW + p) * C) + cc);
-    float a0 = bf_lo(w[0]), a1 = bf_hi(w[0]), a2 = bf_lo(w[1]), a3 = bf_hi(w[1]);
-    float c0 = bf_lo(w[2]), c1 = bf_hi(w[2]), c2 = bf_lo(w[3]), c3 = bf_hi(w[3]);
-    s0 += a0 + a1 + a2 + a3;
-    q0 += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
-    s1 += c0 + c1 + c2 + c3;
-    q1 += c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
-  }
-  red[tid * 4 + 0] = s0; red[tid * 4 + 1] = q0; red[tid * 4 + 2] = s1; red[tid * 4 + 3] = q1;
-  __syncthreads();
-  if (tid < G) {
-    const int ccg = tid >> 1, half = tid & 1;
-    float ts = 0.f, tq = 0.f;
-    for (int r = 0; r < pstep; ++r) {
-      int idx = (r * cpr + ccg) * 4 + half * 2;
-      ts += red[idx];
-      tq += red[idx + 1];
-    }
-    float* o = ws + (((long long)b * nchunks + chunk) * G + tid) * 2;
-    o[0] = ts;
-    o[1] = tq;
-  }
-}
-
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x,
-                                                       const float* __restrict__ ws,
-                                                       const bf16_t* __restrict__ gamma,
-                                                       const bf16_t* __restrict__ beta,
-                                                       bf16_t* __restrict__ out, int HW, int C,
-                                                       int G, int nchunks, float eps, int silu, int ppb) {
-  __shared__ float s_mean[64], s_rstd[64];
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int tid = threadIdx.x;
-  if (tid < G) {   // (mean, rstd) per group, reduced once by gn_finalize_kernel
-    const float* st = ws + ((long long)gridDim.y * nchunks * G + (long long)b * G + tid) * 2;
-    s_mean[tid] = st[0];
-    s_rstd[tid] = st[1];
-  }
-  __syncthreads();
-  const int cpr = C >> 3;
-  const int cc = tid % cpr;
-  const int prow = tid / cpr, pstep = 256 / cpr;
-  const int cg = C / G;
-  u32x4 gw = *((const u32x4*)gamma + cc);
-  u32x4 bw = *((const u32x4*)beta + cc);
-  float mu[8], rs[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    int g = (cc * 8 + e) / cg;
-    mu[e] = s_mean[g];
-    rs[e] = s_rstd[g];
-  }
-  const int p0 = chunk * ppb;
-  const int p1 = min(p0 + ppb, HW);
-  // fold normalisation + affine into one fma per element: y = x * a + c
-  float fa[8], fc[8];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    fa[2 * e] = rs[2 * e] * bf_lo(gw[e]);
-    fa[2 * e + 1] = rs[2 * e + 1] * bf_hi(gw[e]);
-    fc[2 * e] = bf_lo(bw[e]) - mu[2 * e] * fa[2 * e];
-    fc[2 * e + 1] = bf_hi(bw[e]) - mu[2 * e + 1] * fa[2 * e + 1];
-  }
-  constexpr int U = 4;   // independent 16-B loads in flight per thread
-  for (int p = p0 + prow; p < p1; p += pstep * U) {
-    u32x4 w[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int pp = min(p + u * pstep, p1 - 1);
-      w[u] = *((const u32x4*)(x + ((long long)b * HW + pp) * C) + cc);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int pp = p + u * pstep;
-      if (pp >= p1) break;
-      u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float y0 = fmaf(bf_lo(w[u][e]), fa[2 * e], fc[2 * e]);
-        float y1 = fmaf(bf_hi(w[u][e]), fa[2 * e + 1], fc[2 * e + 1]);
-        if (silu) {
-          y0 = silu_f(y0);
-          y1 = silu_f(y1);
-        }
-        o[e] = pack_bf16x2(y0, y1);
-      }
-      *((u32x4*)(out + ((long long)b * HW + pp) * C) + cc) = o;
-    }
-  }
-}
-
-// one wave per (batch, group): deterministic (fixed-order) reduction of the per-chunk partials
-__global__ __launch_bounds__(64) void gn_finalize_kernel(float* __restrict__ ws, int B, int G,
-                                                         int nchunks, float cnt, float eps) {
-  const int i = blockIdx.x, lane = threadIdx.x;
-  const int b = i / G, g = i - b * G;
-  float ts = 0.f, tq = 0.f;
-  for (int k = lane; k < nchunks; k += 64) {
-    const float* o = ws + (((long long)b * nchunks + k) * G + g) * 2;
-    ts += o[0];
-    tq += o[1];
-  }
-  ts = wave_sum(ts);
-  tq = wave_sum(tq);
-  if (lane == 0) {
-    const float mean = ts / cnt;
-    const float var = fmaxf(tq / cnt - mean * mean, 0.f);
-    float* st = ws + ((long long)B * nchunks * G + i) * 2;
-    st[0] = mean;
-    st[1] = rsqrtf(var + eps);
-  }
-}
-
 }  // namespace
 
 extern "C" int fluxhip_ln_modulate_bf16(const void* x, void* out, int B, int Tr, int D, int S,
@@ -399,36 +218,5 @@ extern "C" int fluxhip_qk_norm_rope_bf16(const void* qkv, int ld, int B, int T, 
                      (const bf16_t*)kw_txt, (const bf16_t*)qw_img, (const bf16_t*)kw_img,
                      (const bf16_t*)rope, (long long)rope_bstride, (bf16_t*)Q, (bf16_t*)Kout,
                      (bf16_t*)Vt, Tpad, eps, n_qk);
-  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
-}
-
-extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, const void* beta,
-                                           void* out, int B, int HW, int C, int G, float eps,
-                                           int silu, void* ws, int64_t ws_bytes, void* stream) {
-  if (!x || !gamma || !beta || !out || !ws) return FLUXHIP_EINVAL;
-  if (B < 1 || HW < 1 || C % 8 || G < 1 || G > 64 || C % G) return FLUXHIP_EINVAL;
-  const int cpr = C / 8;
-  if (cpr > 256 || 256 % cpr) return FLUXHIP_EINVAL;
-  const int cg = C / G;
-  if (!(cg == 4 || (cg >= 8 && cg % 8 == 0))) return FLUXHIP_EINVAL;
-  // pixels per block: aim for >= 512 blocks, keep the partial table small
-  int ppb = 1024;
-  while (ppb > 32 && (long long)B * ((HW + ppb - 1) / ppb) < 512) ppb >>= 1;
-  const int nchunks = (HW + ppb - 1) / ppb;
-  if (ws_bytes < ((int64_t)B * nchunks * G + (int64_t)B * G) * 2 * (int64_t)sizeof(float))
-    return FLUXHIP_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(nchunks, B), block(256);
-  if (cg == 4)
-    hipLaunchKernelGGL(gn_partial_cg4_kernel, grid, block, 0, s, (const bf16_t*)x, (float*)ws, HW,
-                       C, G, nchunks, ppb);
-  else
-    hipLaunchKernelGGL(gn_partial_kernel, grid, block, 0, s, (const bf16_t*)x, (float*)ws, HW, C,
-                       G, nchunks, ppb);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, s, (float*)ws, B, G, nchunks,
-                     (float)HW * (float)cg, eps);
-  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, (const bf16_t*)x, (const float*)ws,
-                     (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)out, HW, C, G, nchunks,
-                     eps, silu, ppb);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }

@@ -1,0 +1,200 @@
+// Memory-bound glue kernels of the stable_diffusion/ UNet + sampler path (HBM roofline class).
+#include "../../include/fluxhip.h"
+#include "common.h"
+
+namespace {
+
+// nn.LayerNorm(dims) with affine weight/bias, eps 1e-5 (TransformerBlock.norm1/2/3,
+// stable_diffusion/.../unet.py:45,50,57). One wave per row, NCH 16-byte chunks per lane.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __restrict__ x,
+                                                               bf16_t* __restrict__ out,
+                                                               long long rows, int D,
+                                                               const bf16_t* __restrict__ gamma,
+                                                               const bf16_t* __restrict__ beta,
+                                                               float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * D;
+  bf16_t* orow = out + row * D;
+  const int nchunk = D >> 3;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int c = lane + i * 64;
+    if (c < nchunk) {
+      u32x4 w = *((const u32x4*)xr + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][2 * e] = bf_lo(w[e]);
+        v[i][2 * e + 1] = bf_hi(w[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[i][e];
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int c = lane + i * 64;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = v[i][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int c = lane + i * 64;
+    if (c < nchunk) {
+      u32x4 gw = *((const u32x4*)gamma + c);
+      u32x4 bw = *((const u32x4*)beta + c);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = pack_bf16x2((v[i][2 * e] - mean) * rstd * bf_lo(gw[e]) + bf_lo(bw[e]),
+                           (v[i][2 * e + 1] - mean) * rstd * bf_hi(gw[e]) + bf_hi(bw[e]));
+      *((u32x4*)orow + c) = o;
+    }
+  }
+}
+
+// mx.concatenate([x, res], axis=-1) on NHWC (UNetBlock2D skip connections, unet.py:250) and channel
+// zero-padding (b == nullptr). 4-byte granularity: Ca, Cb even.
+__global__ __launch_bounds__(256) void concat_channels_kernel(const uint32_t* __restrict__ a,
+                                                              const uint32_t* __restrict__ b,
+                                                              uint32_t* __restrict__ out,
+                                                              long long npix, int ca2, int cb2) {
+  const int c2 = ca2 + cb2;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix * c2) return;
+  long long p = i / c2;
+  int c = (int)(i - p * c2);
+  out[i] = c < ca2 ? a[p * ca2 + c] : (b ? b[p * cb2 + (c - ca2)] : 0u);
+}
+
+// out = ca*x + cb*y + cc*z  (SimpleEulerSampler / SimpleEulerAncestralSampler.step with host-computed
+// sigma coefficients, sampler.py:76-105; and CFG: eps_neg + w (eps_text - eps_neg), __init__.py:77-78)
+__global__ __launch_bounds__(256) void axpbypcz_kernel(const bf16_t* __restrict__ x,
+                                                       const bf16_t* __restrict__ y,
+                                                       const bf16_t* __restrict__ z,
+                                                       bf16_t* __restrict__ out, long long n, float ca,
+                                                       float cb, float cc) {
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= n) return;
+  if (i + 1 < n) {
+    uint32_t xv = *(const uint32_t*)(x + i), yv = *(const uint32_t*)(y + i);
+    float o0 = ca * bf_lo(xv) + cb * bf_lo(yv), o1 = ca * bf_hi(xv) + cb * bf_hi(yv);
+    if (z) {
+      uint32_t zv = *(const uint32_t*)(z + i);
+      o0 += cc * bf_lo(zv);
+      o1 += cc * bf_hi(zv);
+    }
+    *(uint32_t*)(out + i) = pack_bf16x2(o0, o1);
+  } else {
+    float o0 = ca * bf2f(x[i]) + cb * bf2f(y[i]) + (z ? cc * bf2f(z[i]) : 0.f);
+    out[i] = f2bf(o0);
+  }
+}
+
+// Per-pixel tiny Linear (Autoencoder.post_quant_proj 4 -> 4 fused with z / scaling_factor, vae.py:256-258)
+// with optional zero padding of the output channels to Cpad (so the following 3x3 conv sees Cin % 8 == 0).
+__global__ __launch_bounds__(256) void pixel_linear_kernel(const bf16_t* __restrict__ x,
+                                                           const bf16_t* __restrict__ w,
+                                                           const bf16_t* __restrict__ bias,
+                                                           bf16_t* __restrict__ out, long long npix,
+                                                           int Cin, int Cout, int Cpad, float in_div) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix * Cpad) return;
+  long long p = i / Cpad;
+  int co = (int)(i - p * Cpad);
+  float acc = 0.f;
+  if (co < Cout) {
+    acc = bias ? bf2f(bias[co]) : 0.f;
+    for (int c = 0; c < Cin; ++c) acc += (bf2f(x[p * Cin + c]) / in_div) * bf2f(w[co * Cin + c]);
+  }
+  out[i] = f2bf(acc);
+}
+
+// nn.SinusoidalPositionalEncoding(cos_first=True): out[n] = [cos(x[n] * sig) | sin(x[n] * sig)]
+// (unet.py:283-292,301-313). x is float32 (timesteps are not bf16-representable), sig comes from the host.
+__global__ __launch_bounds__(256) void sincos_embed_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ sig,
+                                                           bf16_t* __restrict__ out, int n, int half) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * half) return;
+  int r = i / half, k = i - r * half;
+  float a = x[r] * sig[k];
+  out[(long long)r * 2 * half + k] = f2bf(cosf(a));
+  out[(long long)r * 2 * half + half + k] = f2bf(sinf(a));
+}
+
+}  // namespace
+
+extern "C" int fluxhip_layernorm_affine_bf16(const void* x, void* out, int64_t rows, int D,
+                                             const void* gamma, const void* beta, float eps,
+                                             void* stream) {
+  if (!x || !out || !gamma || !beta || rows < 1 || D < 8 || D % 8 || D > 4096) return FLUXHIP_EINVAL;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = (D + 511) / 512;
+#define LNA(NCH)                                                                                  \
+  hipLaunchKernelGGL((layernorm_affine_kernel<NCH>), grid, block, 0, s, (const bf16_t*)x,         \
+                     (bf16_t*)out, (long long)rows, D, (const bf16_t*)gamma, (const bf16_t*)beta, eps)
+  if (nch <= 1) LNA(1);
+  else if (nch <= 2) LNA(2);
+  else if (nch <= 3) LNA(3);
+  else if (nch <= 4) LNA(4);
+  else if (nch <= 6) LNA(6);
+  else LNA(8);
+#undef LNA
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_concat_channels_bf16(const void* a, const void* b, void* out, int64_t npix,
+                                            int Ca, int Cb, void* stream) {
+  if (!a || !out || npix < 1 || Ca < 2 || Cb < 0 || (Ca & 1) || (Cb & 1)) return FLUXHIP_EINVAL;
+  long long total = npix * ((Ca + Cb) / 2);
+  hipLaunchKernelGGL(concat_channels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint32_t*)a, (const uint32_t*)b, (uint32_t*)out,
+                     (long long)npix, Ca / 2, Cb / 2);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_axpbypcz_bf16(const void* x, const void* y, const void* z, void* out,
+                                     int64_t n, float ca, float cb, float cc, void* stream) {
+  if (!x || !y || !out || n < 1) return FLUXHIP_EINVAL;
+  long long threads = (n + 1) / 2;
+  hipLaunchKernelGGL(axpbypcz_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)z,
+                     (bf16_t*)out, (long long)n, ca, cb, cc);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_pixel_linear_bf16(const void* x, const void* w, const void* bias, void* out,
+                                         int64_t npix, int Cin, int Cout, int Cpad, float in_div,
+                                         void* stream) {
+  if (!x || !w || !out || npix < 1 || Cin < 1 || Cin > 64 || Cout < 1 || Cpad < Cout) return FLUXHIP_EINVAL;
+  long long total = npix * Cpad;
+  hipLaunchKernelGGL(pixel_linear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)bias,
+                     (bf16_t*)out, (long long)npix, Cin, Cout, Cpad, in_div == 0.f ? 1.f : in_div);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_sincos_embed_f32(const void* x, const void* sig, void* out, int n, int half,
+                                        void* stream) {
+  if (!x || !sig || !out || n < 1 || half < 1) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL(sincos_embed_kernel, dim3((n * half + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, (const float*)x, (const float*)sig, (bf16_t*)out, n, half);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import GemmDesc
 
-EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU = 0, 1, 2, 3, 4, 5
 BF16 = torch.bfloat16
 
 
@@ -62,6 +62,7 @@ def make_gemm_desc(groups: Sequence[dict], nbatch: int, N: int, K: int, lda: int
         t.A, t.W, t.bias, t.C = g["A"], g["W"], g.get("bias"), g["C"]
         t.res, t.gate = g.get("res"), g.get("gate")
         t.a_bstride, t.c_bstride, t.gate_bstride = g.get("a_bstride", 0), g.get("c_bstride", 0), g.get("gate_bstride", 0)
+        t.w_bstride = g.get("w_bstride", 0)
         t.M = g["M"]
     return d
 
@@ -176,7 +177,8 @@ def _zeros16(device) -> torch.Tensor:
 
 
 def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], stride: int = 1, pad: int = 1, ups: bool = False,
-           res: Optional[torch.Tensor] = None, epi: int = EPI_BIAS, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           res: Optional[torch.Tensor] = None, epi: int = EPI_BIAS, out: Optional[torch.Tensor] = None,
+           addvec: Optional[torch.Tensor] = None) -> torch.Tensor:
     """NHWC conv, w [Cout,kh,kw,Cin] (or [Cout,Cin] for 1x1). res => out = res + conv(x)."""
     _bf16c(x, "x"); _bf16c(w, "w")
     B, Hs, Ws, Cin = x.shape
@@ -192,10 +194,10 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], stride: 
         epi = EPI_GATE_RES
     lib = _lib.load()
     if Cin % 64 == 0 and Cout % 4 == 0:
-        _check(lib.fluxhip_conv2d_bf16(_p(x), _p(w), _p(b), _p(res), _p(out), B, Hs, Ws, Cin, Cout, ks, stride, pad,
+        _check(lib.fluxhip_conv2d_bf16(_p(x), _p(w), _p(b), _p(res), _p(addvec), _p(out), B, Hs, Ws, Cin, Cout, ks, stride, pad,
                                        int(ups), epi, _p(_zeros16(x.device)), _stream()), "fluxhip_conv2d_bf16")
     else:
-        if ks != 3 or stride != 1 or pad != 1 or ups or res is not None:
+        if ks != 3 or stride != 1 or pad != 1 or ups or res is not None or addvec is not None:
             raise FluxHipError("small-channel conv path only supports 3x3/s1/p1")
         _check(lib.fluxhip_conv2d_small(_p(x), _p(w), _p(b), _p(out), B, Hs, Ws, Cin, Cout, 0, 0, _stream()),
                "fluxhip_conv2d_small")
@@ -223,7 +225,7 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     if out is None:
         out = torch.empty_like(x)
     ws = _gn_ws.get(x.device)
-    need = (B * ((H * W_ + 31) // 32) * groups + B * groups) * 2 * 4
+    need = (B * ((H * W_ + 31) // 32) * Cc + B * groups) * 2 * 4
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(max(need // 4, 1 << 18), dtype=torch.float32, device=x.device)
         _gn_ws[x.device] = ws
@@ -245,4 +247,65 @@ def softmax_rows(s: torch.Tensor, scale: float, out: Optional[torch.Tensor] = No
         out = torch.zeros(s.shape, dtype=BF16, device=s.device)
     _check(_lib.load().fluxhip_softmax_rows_f32(_p(s), _p(out), rows, cols, ld, float(scale), _stream()),
            "fluxhip_softmax_rows_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ UNet path
+def attention_strided(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, hd: int,
+                      Tq: int, Tk: int, Tkpad: int, q_strides, k_strides, ldo: int, scale: float) -> None:
+    """q/k addressed as base + b*bs + h*hs + t*rs (element strides); vt [B][H*hd][Tkpad]."""
+    _check(_lib.load().fluxhip_attention_strided_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(vt), _p(out), ldo, B, H,
+                                                      hd, Tq, Tk, Tkpad, float(scale), _stream()),
+           "fluxhip_attention_strided_bf16")
+
+
+def layernorm_affine(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16c(x, "x")
+    D = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    _check(_lib.load().fluxhip_layernorm_affine_bf16(_p(x), _p(out), x.numel() // D, D, _p(gamma), _p(beta), eps,
+                                                     _stream()), "fluxhip_layernorm_affine_bf16")
+    return out
+
+
+def concat_channels(a: torch.Tensor, b: Optional[torch.Tensor], pad_to: int = 0) -> torch.Tensor:
+    """cat([a, b], -1) on [..., C] tensors; b=None zero-pads a to pad_to channels."""
+    _bf16c(a, "a")
+    Ca = a.shape[-1]
+    Cb = b.shape[-1] if b is not None else pad_to - Ca
+    out = torch.empty(*a.shape[:-1], Ca + Cb, dtype=BF16, device=a.device)
+    _check(_lib.load().fluxhip_concat_channels_bf16(_p(a), _p(b), _p(out), a.numel() // Ca, Ca, Cb, _stream()),
+           "fluxhip_concat_channels_bf16")
+    return out
+
+
+def axpbypcz(x: torch.Tensor, y: torch.Tensor, z: Optional[torch.Tensor], ca: float, cb: float, cc: float = 0.0,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16c(x, "x"); _bf16c(y, "y")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(_lib.load().fluxhip_axpbypcz_bf16(_p(x), _p(y), _p(z), _p(out), x.numel(), float(ca), float(cb), float(cc),
+                                             _stream()), "fluxhip_axpbypcz_bf16")
+    return out
+
+
+def pixel_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad_to: int, in_div: float) -> torch.Tensor:
+    _bf16c(x, "x"); _bf16c(w, "w")
+    Cin, Cout = x.shape[-1], w.shape[0]
+    out = torch.empty(*x.shape[:-1], pad_to, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_pixel_linear_bf16(_p(x), _p(w), _p(b), _p(out), x.numel() // Cin, Cin, Cout, pad_to,
+                                                 float(in_div), _stream()), "fluxhip_pixel_linear_bf16")
+    return out
+
+
+def sincos_embed(x: torch.Tensor, sig: torch.Tensor) -> torch.Tensor:
+    """x float32 [n], sig float32 [half] -> bf16 [n, 2*half] = [cos | sin]."""
+    if x.dtype != torch.float32 or sig.dtype != torch.float32:
+        raise FluxHipError("sincos_embed takes float32 inputs")
+    n, half = x.numel(), sig.numel()
+    out = torch.empty(n, 2 * half, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_sincos_embed_f32(_p(x.contiguous()), _p(sig.contiguous()), _p(out), n, half, _stream()),
+           "fluxhip_sincos_embed_f32")
     return out

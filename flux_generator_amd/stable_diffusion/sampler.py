@@ -1,0 +1,84 @@
+"""SimpleEulerSampler / SimpleEulerAncestralSampler (mirror of the reference's
+stable_diffusion/stable_diffusion/sampler.py).  The sigma table and the per-step coefficients are host
+scalars (float32, like the reference); the update itself is one HBM-bound libfluxhip kernel."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import ops
+from .config import DiffusionConfig
+
+
+def _linspace(a, b, num):
+    """sampler.py:8-10."""
+    x = torch.arange(0, num, dtype=torch.float32) / (num - 1)
+    return (b - a) * x + a
+
+
+def _interp(y: torch.Tensor, x_new: torch.Tensor) -> torch.Tensor:
+    """sampler.py:13-23."""
+    x_low = x_new.to(torch.int32).long()
+    x_high = torch.clamp(x_low + 1, max=len(y) - 1)
+    delta = x_new - x_low
+    return y[x_low] * (1 - delta) + delta * y[x_high]
+
+
+class SimpleEulerSampler:
+    def __init__(self, config: DiffusionConfig):
+        if config.beta_schedule == "linear":
+            betas = _linspace(config.beta_start, config.beta_end, config.num_train_steps)
+        elif config.beta_schedule == "scaled_linear":
+            betas = _linspace(config.beta_start ** 0.5, config.beta_end ** 0.5, config.num_train_steps).square()
+        else:
+            raise NotImplementedError(f"{config.beta_schedule} is not implemented.")
+        alphas_cumprod = torch.cumprod(1 - betas, dim=0)
+        self._sigmas = torch.cat([torch.zeros(1), ((1 - alphas_cumprod) / alphas_cumprod).sqrt()])
+
+    @property
+    def max_time(self):
+        return len(self._sigmas) - 1
+
+    def sample_prior(self, shape, dtype=torch.bfloat16, key: Optional[torch.Generator] = None, device="cuda"):
+        """sampler.py:56-60: N(0,1) * sigma_max / sqrt(sigma_max^2 + 1)."""
+        noise = torch.randn(shape, generator=key, device=device, dtype=torch.float32)
+        s = self._sigmas[-1]
+        return (noise * float(s * torch.rsqrt(s.square() + 1))).to(dtype)
+
+    def sigmas(self, t) -> torch.Tensor:
+        return _interp(self._sigmas, torch.as_tensor(t, dtype=torch.float32))
+
+    def timesteps(self, num_steps: int, start_time=None, dtype=torch.float32):
+        """sampler.py:70-74 (the timestep values are rounded to `dtype` like the reference's astype)."""
+        start_time = start_time or (len(self._sigmas) - 1)
+        assert 0 < start_time <= (len(self._sigmas) - 1)
+        steps = _linspace(start_time, 0, num_steps + 1).to(dtype).to(torch.float32).tolist()
+        return list(zip(steps, steps[1:]))
+
+    def _coeffs(self, t, t_prev):
+        sigma, sigma_prev = self.sigmas(t), self.sigmas(t_prev)
+        inv = torch.rsqrt(sigma_prev.square() + 1)
+        return float((sigma.square() + 1).sqrt() * inv), float((sigma_prev - sigma) * inv), 0.0
+
+    def step(self, eps_pred: torch.Tensor, x_t: torch.Tensor, t, t_prev, noise: Optional[torch.Tensor] = None):
+        """sampler.py:76-85: ((sigma^2+1)^.5 x + eps (sigma_prev - sigma)) (sigma_prev^2+1)^-.5"""
+        ca, cb, _ = self._coeffs(t, t_prev)
+        return ops.axpbypcz(x_t, eps_pred, None, ca, cb)
+
+
+class SimpleEulerAncestralSampler(SimpleEulerSampler):
+    def _coeffs(self, t, t_prev):
+        sigma, sigma_prev = self.sigmas(t), self.sigmas(t_prev)
+        sigma2, sigma_prev2 = sigma.square(), sigma_prev.square()
+        sigma_up = (sigma_prev2 * (sigma2 - sigma_prev2) / sigma2).sqrt()
+        sigma_down = (sigma_prev2 - sigma_up ** 2).sqrt()
+        inv = torch.rsqrt(sigma_prev2 + 1)
+        return float((sigma2 + 1).sqrt() * inv), float((sigma_down - sigma) * inv), float(sigma_up * inv)
+
+    def step(self, eps_pred, x_t, t, t_prev, noise: Optional[torch.Tensor] = None):
+        """sampler.py:89-105; draws the fresh N(0,1) itself unless `noise` is given (parity tests)."""
+        ca, cb, cc = self._coeffs(t, t_prev)
+        if noise is None:
+            noise = torch.randn(x_t.shape, device=x_t.device, dtype=torch.float32).to(x_t.dtype)
+        return ops.axpbypcz(x_t, eps_pred, noise.contiguous(), ca, cb, cc)

@@ -31,7 +31,8 @@ enum {
   FLUXHIP_EPI_GELU_TANH = 1,  /* C = gelu_tanh(A W^T + b)            nn.GELU(approx="tanh")    */
   FLUXHIP_EPI_GATE_RES = 2,   /* C = res + gate * (A W^T + b)        x + mod.gate * proj(...)  */
   FLUXHIP_EPI_SPLIT_GELU = 3, /* cols <  n_split -> C ; cols >= n_split -> gelu_tanh -> C2     */
-  FLUXHIP_EPI_SILU = 4        /* C = silu(A W^T + b)                                            */
+  FLUXHIP_EPI_SILU = 4,       /* C = silu(A W^T + b)                                            */
+  FLUXHIP_EPI_GEGLU = 5       /* C = res * gelu_erf(A W^T + b)       UNet GEGLU (unet.py:74-78) */
 };
 
 /* One operand group of a (possibly grouped) GEMM. Two groups share N, K, the epilogue and the
@@ -47,6 +48,7 @@ typedef struct fluxhip_gemm_group {
   int64_t a_bstride;     /* elements between batches of A                                 */
   int64_t c_bstride;     /* elements between batches of C / res                           */
   int64_t gate_bstride;  /* elements between batches of gate                              */
+  int64_t w_bstride;     /* elements between batches of W (0 = one shared weight)         */
   int32_t M;             /* rows per batch                                                */
   int32_t _pad;
 } fluxhip_gemm_group;
@@ -82,11 +84,14 @@ int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads);
  * ksize 1|3, stride 1|2, pad 0|1, ups=1 fuses upsample_nearest(x,(2,2)) into the loader.
  * out = epi(conv(x) + bias [+ res]).  Replaces nn.Conv2d / Upsample in
  * flux/autoencoder.py:70-81,117-122,224-226,269 and the UNet/VAE convs of stable_diffusion/.
+ * addvec: optional bf16 [B][Cout] added per image after the bias (ResnetBlock2D's time embedding,
+ * stable_diffusion/.../unet.py:161-162).
  * Cin % 64 == 0, Cout % 4 == 0 (the 16->512 conv_in and 128->3 conv_out use the two
  * dedicated entry points below). */
-int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bias, const void* res, void* out,
-                        int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int pad,
-                        int ups, int epi, const void* zero16, void* stream);
+int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bias, const void* res,
+                        const void* addvec, void* out, int B, int Hs, int Ws, int Cin, int Cout,
+                        int ksize, int stride, int pad, int ups, int epi, const void* zero16,
+                        void* stream);
 /* Direct conv for tiny channel counts (Cin*9 not a multiple of 64, or Cout < 4). fp32 accumulate.
  * out_f32 != 0 writes float32 (the decoder's final image), optionally clip((y+1),0,2)*0.5
  * (flux/flux.py:162) when clip01 != 0. */
@@ -158,6 +163,40 @@ int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, const void* be
  * Used by the single-head VAE AttnBlock (flux/autoencoder.py:49).  ld: row stride of S and P. */
 int fluxhip_softmax_rows_f32(const void* s, void* p, int64_t rows, int cols, int ld, float scale,
                              void* stream);
+
+
+/* ---- stable_diffusion/ UNet path ---------------------------------- */
+
+/* Attention with explicit (batch, head, row) element strides for Q and K and head_dim 64 or 128:
+ * O[b, t, h*hd:(h+1)*hd] = softmax(scale * Q K^T) V, V given transposed as Vt [B][H*hd][Tkpad]
+ * (zero padded keys).  Self- and cross-attention of nn.MultiHeadAttention in TransformerBlock
+ * (stable_diffusion/stable_diffusion/unet.py:46-54,64-71; no masks are ever passed, unet.py:403-411). */
+int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                   const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                   const void* Vt, void* O, int ldo, int B, int H, int head_dim,
+                                   int Tq, int Tk, int Tkpad, float scale, void* stream);
+
+/* nn.LayerNorm(D) with affine gamma/beta (unet.py:45,50,57), rows of width D <= 4096. */
+int fluxhip_layernorm_affine_bf16(const void* x, void* out, int64_t rows, int D, const void* gamma,
+                                  const void* beta, float eps, void* stream);
+
+/* out[p] = [a[p, :Ca] | b[p, :Cb]] (mx.concatenate(axis=-1), unet.py:250); b == NULL pads with zeros. */
+int fluxhip_concat_channels_bf16(const void* a, const void* b, void* out, int64_t npix, int Ca,
+                                 int Cb, void* stream);
+
+/* out = ca*x + cb*y + cc*z (z may be NULL).  SimpleEuler(Ancestral)Sampler.step with host-computed
+ * sigma coefficients (sampler.py:76-105) and classifier-free guidance (__init__.py:77-78). */
+int fluxhip_axpbypcz_bf16(const void* x, const void* y, const void* z, void* out, int64_t n, float ca,
+                          float cb, float cc, void* stream);
+
+/* Per-pixel Linear for tiny channel counts: out[p, :Cout] = W (x[p] / in_div) + bias, zero padded to
+ * Cpad channels.  Autoencoder.decode's z / scaling_factor + post_quant_proj (vae.py:256-258). */
+int fluxhip_pixel_linear_bf16(const void* x, const void* w, const void* bias, void* out, int64_t npix,
+                              int Cin, int Cout, int Cpad, float in_div, void* stream);
+
+/* nn.SinusoidalPositionalEncoding(cos_first=True): out[n] = [cos(x[n]*sig) | sin(x[n]*sig)], x and
+ * sig float32, out bf16 [n][2*half] (unet.py:283-292,301-313,413,419). */
+int fluxhip_sincos_embed_f32(const void* x, const void* sig, void* out, int n, int half, void* stream);
 
 #ifdef __cplusplus
 }

@@ -31,10 +31,10 @@ def test_loader_checks_abi_and_arch():
 
 
 def test_gemm_desc_layout_matches_header():
-    """sizeof/offsets of the ctypes mirror = the C struct (LP64): 2 x 80-byte groups + 72 bytes."""
+    """sizeof/offsets of the ctypes mirror = the C struct (LP64): 2 x 88-byte groups + 72 bytes."""
     from flux_generator_amd._lib import GemmDesc, GemmGroup
-    assert ctypes.sizeof(GemmGroup) == 80 and GemmGroup.M.offset == 72
-    assert ctypes.sizeof(GemmDesc) == 232 and GemmDesc.C2.offset == 200 and GemmDesc.alpha.offset == 224
+    assert ctypes.sizeof(GemmGroup) == 88 and GemmGroup.M.offset == 80
+    assert ctypes.sizeof(GemmDesc) == 248 and GemmDesc.C2.offset == 216 and GemmDesc.alpha.offset == 240
 
 
 def test_tile_picker_is_host_only():
