@@ -183,14 +183,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   auto stage = [&](int kt, int buf) {
     char* sa = smem + buf * STAGE_BYTES;
     char* sb = sa + A_BYTES;
+    int koff = kt * BK;                      // K offset (elements) of this step inside a W row
     if (AMODE == 0) {
 #pragma unroll
       for (int i = 0; i < APW; ++i)
         glds16(asrc[i] + (long long)kt * (BK * 2), sa + (wave + i * NWAVES) * 1024);
     } else {
-      const int kpc = p.cv.Cin >> 6;          // K-steps per filter tap
-      const int tap = kt / kpc;
-      const int c0 = (kt - tap * kpc) << 6;
+      // K order = channel chunk outer, filter tap inner: the 9 taps of one 64-channel chunk are
+      // staged back to back, so their overlapping input rows are still in L1/L2 (a tap-major order
+      // re-streams the whole input tile 9 times through the XCD's L2).  The weight operand follows
+      // with a pure index remap: column = tap*Cin + c0 of the [N][kh*kw*Cin] matrix.
+      const int ntap = p.cv.ksize * p.cv.ksize;
+      const int cch = kt / ntap;
+      const int tap = kt - cch * ntap;
+      const int c0 = cch << 6;
+      koff = tap * p.cv.Cin + c0;
       const int dy = (p.cv.ksize == 3) ? tap / 3 : 0;
       const int dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
       const int Hl = p.cv.ups ? p.cv.Hs * 2 : p.cv.Hs;   // logical input grid
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     }
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
-      glds16(bsrc[i] + (long long)kt * (BK * 2), sb + min(wave + i * NWAVES, BPIECES - 1) * 1024);
+      glds16(bsrc[i] + (long long)koff * 2, sb + min(wave + i * NWAVES, BPIECES - 1) * 1024);
   };
 
   // ---- fragment read offsets (same XOR as the staging source swizzle) ---------

@@ -16,10 +16,12 @@ from .sampler import SimpleEulerAncestralSampler, SimpleEulerSampler
 
 
 class StableDiffusion:
-    def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda"):
+    def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True):
         # the HIP path computes in bf16 storage / fp32 accumulate whatever `float16` says
         self.dtype = torch.bfloat16
         self.device = torch.device(device)
+        self.use_graph = use_graph
+        self._graphs = {}
         self.diffusion_config = load_diffusion_config(model)
         self.unet = load_unet(model, float16, device=device)
         self.text_encoder = load_text_encoder(model, float16, device=device)
@@ -47,7 +49,38 @@ class StableDiffusion:
         return conditioning
 
     def _denoising_step(self, x_t, t, t_prev, conditioning, cfg_weight: float = 7.5, text_time=None, noise=None):
-        """__init__.py:67-82: CFG doubles the batch (text first, negative second)."""
+        """__init__.py:67-82.  One UNet step is ~1700 kernel launches; with use_graph they are captured once
+        per (shape, t, t_prev, cfg) into a hipGraph over static input buffers and replayed."""
+        if not self.use_graph or noise is not None:
+            return self._denoising_step_eager(x_t, t, t_prev, conditioning, cfg_weight, text_time, noise)
+        key = (tuple(x_t.shape), tuple(conditioning.shape), float(t), float(t_prev), float(cfg_weight), text_time is not None)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 64:
+                self._graphs.clear()
+            sx, sc = x_t.clone(), conditioning.clone()
+            stt = None if text_time is None else (text_time[0].clone(), text_time[1].clone())
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._denoising_step_eager(sx, t, t_prev, sc, cfg_weight, stt)      # warm-up
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._denoising_step_eager(sx, t, t_prev, sc, cfg_weight, stt)
+            ent = (g, sx, sc, stt, out)
+            self._graphs[key] = ent
+        g, sx, sc, stt, out = ent
+        sx.copy_(x_t)
+        sc.copy_(conditioning)
+        if stt is not None:
+            stt[0].copy_(text_time[0])
+            stt[1].copy_(text_time[1])
+        g.replay()
+        return out.clone()
+
+    def _denoising_step_eager(self, x_t, t, t_prev, conditioning, cfg_weight: float = 7.5, text_time=None, noise=None):
+        """CFG doubles the batch (text first, negative second)."""
         x_unet = torch.cat([x_t] * 2, dim=0) if cfg_weight > 1 else x_t
         t_unet = torch.full((len(x_unet),), float(t), dtype=torch.float32, device=x_t.device)
         eps = self.unet(x_unet, t_unet, encoder_x=conditioning, text_time=text_time)
@@ -76,12 +109,31 @@ class StableDiffusion:
 
     def decode(self, x_t):
         """__init__.py:166-169: clip(vae.decode(x_t) / 2 + 0.5, 0, 1), fused into the last conv."""
-        return self.autoencoder.decode_image(x_t)
+        if not self.use_graph:
+            return self.autoencoder.decode_image(x_t)
+        key = ("decode", tuple(x_t.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            sx = x_t.to(self.dtype).contiguous().clone()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.autoencoder.decode_image(sx)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.autoencoder.decode_image(sx)
+            ent = (g, sx, out)
+            self._graphs[key] = ent
+        g, sx, out = ent
+        sx.copy_(x_t)
+        g.replay()
+        return out.clone()
 
 
 class StableDiffusionXL(StableDiffusion):
-    def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda"):
-        super().__init__(model, float16, device)
+    def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True):
+        super().__init__(model, float16, device, use_graph)
         self.sampler = SimpleEulerAncestralSampler(self.diffusion_config)
         self.text_encoder_1 = self.text_encoder
         self.tokenizer_1 = self.tokenizer

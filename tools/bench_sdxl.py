@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""BASELINE.json config C4: stabilityai/sdxl-turbo 512x512 1-step, batch 16, 1 x MI355X (random-init weights,
+synthetic conditioning resident in HBM).  Prints one JSON line (images/sec, UNet step ms, decode ms)."""
+import json, os, sys, time, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+warnings.simplefilter("ignore")
+from flux_generator_amd.stable_diffusion import StableDiffusionXL
+
+B = int(os.environ.get("SDXL_BATCH", "16"))
+steps = int(os.environ.get("SDXL_ITERS", "5"))
+dev = torch.device("cuda:0")
+pipe = StableDiffusionXL("stabilityai/sdxl-turbo", float16=True)
+g = torch.Generator(device=dev).manual_seed(0)
+x_T = pipe.sampler.sample_prior((B, 64, 64, 4), key=g, device=dev)
+cond = torch.randn(B, 77, 2048, generator=g, device=dev).to(torch.bfloat16)
+pooled = torch.randn(B, 1280, generator=g, device=dev).to(torch.bfloat16)
+tt = (pooled, torch.tensor([[512, 512, 0, 0, 512, 512.0]] * B, device=dev))
+(t, tp), = pipe.sampler.timesteps(1)
+
+def one():
+    x = pipe._denoising_step(x_T, t, tp, cond, 0.0, tt)
+    return pipe.decode(x)
+
+for _ in range(2):
+    img = one()
+torch.cuda.synchronize()
+if os.environ.get("PROFILE_ONLY"):
+    one(); torch.cuda.synchronize(); sys.exit(0)
+t0 = time.perf_counter()
+for _ in range(steps):
+    img = one()
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+e0.record(); x = pipe._denoising_step(x_T, t, tp, cond, 0.0, tt); e1.record(); pipe.decode(x); e2.record()
+torch.cuda.synchronize()
+unet_flop = 1.59e12 * B
+print(json.dumps({"workload": f"sdxl-turbo 512x512 1-step batch {B}", "images_per_sec": B * steps / el,
+                  "unet_step_ms": e0.elapsed_time(e1), "vae_decode_ms": e1.elapsed_time(e2),
+                  "unet_tflops": unet_flop / (e0.elapsed_time(e1) * 1e-3) / 1e12, "finite": bool(torch.isfinite(img).all())}))
