@@ -41,6 +41,8 @@ const TileCfg kCfgs[] = {
     make_cfg<256, 192, 4, 2, 2, 1>(),  // 19: 9216 = 48 x 192 -> 240 tiles at M = 1280
     make_cfg<128, 128, 4, 2, 3, 1>(),  // 20: 8 waves x (32x64), 3-deep ring
     make_cfg<128, 192, 2, 2, 3, 1>(),  // 21: 4 waves x (64x96), 120 KiB
+    make_cfg<256, 256, 2, 2, 2, 1>(),  // 22: 4 waves x (128x128): one wave per SIMD, 512-register waves
+    make_cfg<256, 160, 4, 2, 3, 1>(),  // 23: 3-deep ring, 156 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

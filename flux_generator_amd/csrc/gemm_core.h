@@ -276,8 +276,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     // clusters of a step, so LDS latency and barrier skew hide under 32..64 MFMAs.
     // The fragment reads are inline asm with hand-counted lgkmcnt: hipcc's own bookkeeping drains
     // lgkmcnt(0) at the loop head, which serialises [reads -> wait -> MFMAs] inside each wave.
-    constexpr int NF = MI + NJ;
-    static_assert(NF <= 15, "lgkmcnt field");
+    // lgkmcnt is a 4-bit field: with 16 fragment reads per cluster the wait below asks for <= 15
+    // outstanding, i.e. it also waits for the first read of the NEXT cluster (reads retire in order).
+    constexpr int NF = (MI + NJ) < 15 ? (MI + NJ) : 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t a_rd = lds0 + (wm * WTM) * 128;             // + slot*STAGE_BYTES + foff[kk]
     const uint32_t b_rd = lds0 + A_BYTES + (wn * WTN) * 128;
