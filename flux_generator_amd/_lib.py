@@ -67,6 +67,10 @@ SIGNATURES = {
     "fluxhip_axpbypcz_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_float, c_float, c_float, c_void_p]),
     "fluxhip_pixel_linear_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     "fluxhip_sincos_embed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fluxhip_attention_masked_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                              c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p, c_int, c_void_p]),
+    "fluxhip_rmsnorm_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_float, c_void_p]),
+    "fluxhip_embedding_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "fluxhip_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
 }
 

@@ -34,9 +34,14 @@ struct AttnParams {
   long long k_bs, k_hs, k_rs;
   int ldo, H, Tq, Tk, Tkpad, nqb;
   float scale_log2;
+  float scale;              // MODE 1: logits = scale * q.k + bias
+  const bf16_t* bias;       // MODE 1: additive bias [H][Tq][Tk] (T5 relative position bias)
 };
 
-template <int HD, int NW>
+// MODE 0: plain; MODE 1: additive per-head bias (flux/t5.py:70-116,153-155: scale 1.0, bias passed as
+// the SDPA mask); MODE 2: causal (CLIP text model, flux/clip.py:91-95: key index > query index masked)
+
+template <int HD, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   constexpr int RB = HD * 2;                  // bytes per K row
   constexpr int CPR = RB / 16;                // 16-B chunks per K row
@@ -121,8 +126,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   const int v_rowoff = ql * 128 + hi * 8;
   const int v_sw = (ql >> 1) & 7;
 
-  const int ntiles = (Tk + KV - 1) / KV;
-  const float scale_log2 = p.scale_log2;
+  int ntiles = (Tk + KV - 1) / KV;
+  // causal: keys beyond the workgroup's last query row are all masked (block-uniform trip count:
+  // every wave must reach the same barriers)
+  if (MODE == 2) ntiles = min(ntiles, min(qb * (NW * 32) + NW * 32 - 1, Tq - 1) / KV + 1);
+  const float scale_log2 = (MODE == 1) ? 1.4426950408889634f : p.scale_log2;
+  const bf16_t* bias_q = (MODE == 1) ? p.bias + ((long long)h * Tq + qrow) * Tk : nullptr;
   stage(0, 0);
   wait_vm0();
   __syncthreads();
@@ -145,8 +154,36 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
         sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sT[kb], 0, 0, 0);
       }
     }
-    // ---- mask the key tail (last tile only) ----------------------------------
     const int key0 = it * KV;
+    if (MODE == 1) {   // logits = scale * s + bias[h][q][key]; 4 consecutive keys per 8-byte load
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int key = key0 + kb * 32 + 8 * rg + 4 * hi;
+          float b4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (key + 3 < Tk) {
+            u32x2 bw = *(const u32x2*)(bias_q + key);
+            b4[0] = bf_lo(bw[0]); b4[1] = bf_hi(bw[0]); b4[2] = bf_lo(bw[1]); b4[3] = bf_hi(bw[1]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (key + e < Tk) b4[e] = bf2f(bias_q[key + e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sT[kb][rg * 4 + e] = fmaf(sT[kb][rg * 4 + e], p.scale, b4[e]);
+        }
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key > q0 + ql) sT[kb][r] = -1e30f;
+        }
+    }
+    // ---- mask the key tail (last tile only) ----------------------------------
     if (key0 + KV > Tk) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -229,14 +266,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   }
 }
 
-bool g_attr_done[2] = {false, false};
+bool g_attr_done[2][3] = {};
 
-template <int HD>
+template <int HD, int MODE>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
   constexpr int NW = 4;
   constexpr int lds = 2 * (KV * HD * 2 + HD * KV * 2);
-  auto fn = attn_kernel<HD, NW>;
-  bool& done = g_attr_done[HD == 128 ? 0 : 1];
+  auto fn = attn_kernel<HD, NW, MODE>;
+  bool& done = g_attr_done[HD == 128 ? 0 : 1][MODE];
   if (!done) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return FLUXHIP_ELAUNCH;
@@ -261,7 +298,7 @@ extern "C" int fluxhip_attention_d128_bf16(const void* Q, const void* K, const v
   p.ldo = ldo; p.H = H; p.Tq = T; p.Tk = T; p.Tkpad = Tpad;
   p.nqb = (T + 127) / 128;
   p.scale_log2 = scale * 1.4426950408889634f;
-  return launch_attn<128>(p, B, (hipStream_t)stream);
+  return launch_attn<128, 0>(p, B, (hipStream_t)stream);
 }
 
 extern "C" int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
@@ -281,6 +318,28 @@ extern "C" int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64
   p.ldo = ldo; p.H = H; p.Tq = Tq; p.Tk = Tk; p.Tkpad = Tkpad;
   p.nqb = (Tq + 127) / 128;
   p.scale_log2 = scale * 1.4426950408889634f;
-  return head_dim == 128 ? launch_attn<128>(p, B, (hipStream_t)stream)
-                         : launch_attn<64>(p, B, (hipStream_t)stream);
+  return head_dim == 128 ? launch_attn<128, 0>(p, B, (hipStream_t)stream)
+                         : launch_attn<64, 0>(p, B, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_attention_masked_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                             const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                             const void* Vt, void* O, int ldo, int B, int H, int Tq,
+                                             int Tk, int Tkpad, float scale, const void* bias,
+                                             int causal, void* stream) {
+  if (!Q || !K || !Vt || !O || B < 1 || H < 1 || Tq < 1 || Tk < 1 || Tkpad % 64 || Tkpad < Tk)
+    return FLUXHIP_EINVAL;
+  if (ldo % 4 || q_rs % 8 || k_rs % 8 || q_hs % 8 || k_hs % 8 || q_bs % 8 || k_bs % 8) return FLUXHIP_EINVAL;
+  if ((bias != nullptr) == (causal != 0)) return FLUXHIP_EINVAL;   // exactly one of the two
+  if (bias && (Tk % 4)) return FLUXHIP_EINVAL;
+  AttnParams p{};
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
+  p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
+  p.ldo = ldo; p.H = H; p.Tq = Tq; p.Tk = Tk; p.Tkpad = Tkpad;
+  p.nqb = (Tq + 127) / 128;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.scale = scale;
+  p.bias = (const bf16_t*)bias;
+  return bias ? launch_attn<64, 1>(p, B, (hipStream_t)stream) : launch_attn<64, 2>(p, B, (hipStream_t)stream);
 }

@@ -31,6 +31,7 @@ enum GemmEpi : int {
                       // n >= n_split: C2[:, n - n_split + c2_coloff] = gelu_tanh(acc + bias)
   EPI_SILU = 4,       // C = silu(acc + bias)
   EPI_GEGLU = 5,      // C = res * gelu_erf(acc + bias)       (UNet GEGLU: linear1(y) * gelu(linear2(y)))
+  EPI_QUICK_GELU = 6, // C = v * sigmoid(1.702 v), v = acc + bias   (CLIP "quick_gelu", flux/clip.py:9)
 };
 
 struct GemmGroup {
@@ -372,6 +373,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       } else if (epi == EPI_SILU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(rbf(v[r]));
+      } else if (epi == EPI_QUICK_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = rbf(v[r]);
+          v[r] = t / (1.0f + __expf(-1.702f * t));
+        }
       } else if (epi == EPI_GATE_RES) {
         const bf16_t* rp = gRes + (long long)b * c_bs + (long long)m * p.ldc + n4;
         u32x2 rw = *(const u32x2*)rp;

@@ -12,7 +12,9 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __r
                                                                long long rows, int D,
                                                                const bf16_t* __restrict__ gamma,
                                                                const bf16_t* __restrict__ beta,
-                                                               float eps) {
+                                                               float eps, int rms) {
+  // rms != 0: nn.RMSNorm (x * rsqrt(mean(x^2) + eps) * gamma, no mean subtraction, no beta;
+  // flux/t5.py:196-197,216)
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __r
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += v[i][e];
   }
-  const float mean = wave_sum(sum) / (float)D;
+  const float mean = rms ? 0.f : wave_sum(sum) / (float)D;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __r
     int c = lane + i * 64;
     if (c < nchunk) {
       u32x4 gw = *((const u32x4*)gamma + c);
-      u32x4 bw = *((const u32x4*)beta + c);
+      u32x4 bw = beta ? *((const u32x4*)beta + c) : u32x4{0, 0, 0, 0};
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -138,18 +140,41 @@ __global__ __launch_bounds__(256) void sincos_embed_kernel(const float* __restri
   out[(long long)r * 2 * half + half + k] = f2bf(sinf(a));
 }
 
+// nn.Embedding lookup (+ optional learned position embedding added per position): out[i] = table[idx[i]]
+// (+ pos[i % T]).  flux/t5.py:229,243 (wte), flux/clip.py:83-84,134-135; also used to gather the pooled
+// EOS rows (flux/clip.py:148).  16-byte chunks, one thread per chunk.
+__global__ __launch_bounds__(256) void embedding_kernel(const int* __restrict__ idx,
+                                                        const bf16_t* __restrict__ table,
+                                                        const bf16_t* __restrict__ pos,
+                                                        bf16_t* __restrict__ out, long long n, int D,
+                                                        int T, int V) {
+  const int cpr = D >> 3;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * cpr) return;
+  long long r = i / cpr;
+  int c = (int)(i - r * cpr);
+  int id = min(max(idx[r], 0), V - 1);
+  u32x4 w = *((const u32x4*)(table + (long long)id * D) + c);
+  if (pos) {
+    u32x4 pw = *((const u32x4*)(pos + (long long)(r % T) * D) + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      w[e] = pack_bf16x2(bf_lo(w[e]) + bf_lo(pw[e]), bf_hi(w[e]) + bf_hi(pw[e]));
+  }
+  *((u32x4*)(out + r * D) + c) = w;
+}
+
 }  // namespace
 
-extern "C" int fluxhip_layernorm_affine_bf16(const void* x, void* out, int64_t rows, int D,
-                                             const void* gamma, const void* beta, float eps,
-                                             void* stream) {
-  if (!x || !out || !gamma || !beta || rows < 1 || D < 8 || D % 8 || D > 4096) return FLUXHIP_EINVAL;
+static int run_layernorm(const void* x, void* out, int64_t rows, int D, const void* gamma, const void* beta,
+                         float eps, int rms, void* stream) {
+  if (!x || !out || !gamma || (!beta && !rms) || rows < 1 || D < 8 || D % 8 || D > 4096) return FLUXHIP_EINVAL;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   const int nch = (D + 511) / 512;
 #define LNA(NCH)                                                                                  \
   hipLaunchKernelGGL((layernorm_affine_kernel<NCH>), grid, block, 0, s, (const bf16_t*)x,         \
-                     (bf16_t*)out, (long long)rows, D, (const bf16_t*)gamma, (const bf16_t*)beta, eps)
+                     (bf16_t*)out, (long long)rows, D, (const bf16_t*)gamma, (const bf16_t*)beta, eps, rms)
   if (nch <= 1) LNA(1);
   else if (nch <= 2) LNA(2);
   else if (nch <= 3) LNA(3);
@@ -158,6 +183,17 @@ extern "C" int fluxhip_layernorm_affine_bf16(const void* x, void* out, int64_t r
   else LNA(8);
 #undef LNA
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_layernorm_affine_bf16(const void* x, void* out, int64_t rows, int D,
+                                             const void* gamma, const void* beta, float eps,
+                                             void* stream) {
+  return run_layernorm(x, out, rows, D, gamma, beta, eps, 0, stream);
+}
+
+extern "C" int fluxhip_rmsnorm_bf16(const void* x, void* out, int64_t rows, int D, const void* gamma,
+                                    float eps, void* stream) {
+  return run_layernorm(x, out, rows, D, gamma, nullptr, eps, 1, stream);
 }
 
 extern "C" int fluxhip_concat_channels_bf16(const void* a, const void* b, void* out, int64_t npix,
@@ -196,5 +232,15 @@ extern "C" int fluxhip_sincos_embed_f32(const void* x, const void* sig, void* ou
   if (!x || !sig || !out || n < 1 || half < 1) return FLUXHIP_EINVAL;
   hipLaunchKernelGGL(sincos_embed_kernel, dim3((n * half + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, (const float*)x, (const float*)sig, (bf16_t*)out, n, half);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_embedding_bf16(const void* idx, const void* table, const void* pos, void* out,
+                                      int64_t n, int D, int T, int V, void* stream) {
+  if (!idx || !table || !out || n < 1 || D < 8 || D % 8 || V < 1 || (pos && T < 1)) return FLUXHIP_EINVAL;
+  long long total = n * (D / 8);
+  hipLaunchKernelGGL(embedding_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const int*)idx, (const bf16_t*)table, (const bf16_t*)pos,
+                     (bf16_t*)out, (long long)n, D, T > 0 ? T : 1, V);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }

@@ -1,0 +1,161 @@
+"""CLIP text model on MI355X — host-side mirror of the reference's flux/clip.py (CLIPTextModelConfig,
+CLIPOutput, CLIPTextModel.sanitize/__call__).  LayerNorm kernel -> fused [q;k] GEMM (+bias) + V^T GEMM
+(row bias) -> causal head_dim-64 flash attention -> out_proj + residual epilogue -> LayerNorm ->
+linear1 with the quick_gelu epilogue -> linear2 + residual; pooled output = row at argmax(token id)."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from .. import _lib, ops
+from ..ops import EPI_GATE_RES, EPI_QUICK_GELU, FluxHipError, make_gemm_desc
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class CLIPTextModelConfig:
+    """flux/clip.py:12-30."""
+    num_layers: int = 23
+    model_dims: int = 1024
+    num_heads: int = 16
+    max_length: int = 77
+    vocab_size: int = 49408
+    hidden_act: str = "quick_gelu"
+
+    @classmethod
+    def from_dict(cls, config):
+        return cls(num_layers=config["num_hidden_layers"], model_dims=config["hidden_size"],
+                   num_heads=config["num_attention_heads"], max_length=config["max_position_embeddings"],
+                   vocab_size=config["vocab_size"], hidden_act=config["hidden_act"])
+
+
+# openai/clip-vit-large-patch14 text tower as shipped in FLUX.1 text_encoder/config.json
+CLIP_L = dict(num_layers=12, model_dims=768, num_heads=12, max_length=77, vocab_size=49408, hidden_act="quick_gelu")
+
+
+@dataclass
+class CLIPOutput:
+    pooled_output: Optional[torch.Tensor] = None
+    last_hidden_state: Optional[torch.Tensor] = None
+    hidden_states: Optional[List[torch.Tensor]] = None
+
+
+class CLIPTextModel:
+    def __init__(self, config: CLIPTextModelConfig, device: Union[str, torch.device] = "cuda"):
+        if config.model_dims // config.num_heads != 64:
+            raise ValueError("libfluxhip CLIP attention is built for head_dim 64")
+        if config.hidden_act != "quick_gelu":
+            raise ValueError("only quick_gelu (the FLUX.1 CLIP-L text tower) is built")
+        self.config = config
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise FluxHipError("CLIPTextModel needs a HIP device")
+        _lib.load()
+        D = config.model_dims
+        shp = {"token_embedding.weight": (config.vocab_size, D), "position_embedding.weight": (config.max_length, D),
+               "final_layer_norm.weight": (D,), "final_layer_norm.bias": (D,)}
+        for i in range(config.num_layers):
+            p = f"layers.{i}"
+            for n in ("layer_norm1", "layer_norm2"):
+                shp[f"{p}.{n}.weight"] = (D,); shp[f"{p}.{n}.bias"] = (D,)
+            for n in ("query_proj", "key_proj", "value_proj", "out_proj"):
+                shp[f"{p}.attention.{n}.weight"] = (D, D); shp[f"{p}.attention.{n}.bias"] = (D,)
+            shp[f"{p}.linear1.weight"] = (4 * D, D); shp[f"{p}.linear1.bias"] = (4 * D,)
+            shp[f"{p}.linear2.weight"] = (D, 4 * D); shp[f"{p}.linear2.bias"] = (D,)
+        self._params = {k: torch.empty(*v, dtype=BF16, device=self.device) for k, v in shp.items()}
+        self._qk: Dict[int, tuple] = {}
+
+    def parameters(self):
+        return self._params
+
+    def sanitize(self, weights):
+        """flux/clip.py:96-125."""
+        out = {}
+        for key, w in weights.items():
+            for pre in ("text_model.", "embeddings.", "encoder."):
+                if key.startswith(pre):
+                    key = key[len(pre):]
+            for a, b in (("self_attn.", "attention."), ("q_proj.", "query_proj."), ("k_proj.", "key_proj."),
+                         ("v_proj.", "value_proj."), ("mlp.fc1", "linear1"), ("mlp.fc2", "linear2")):
+                if a in key:
+                    key = key.replace(a, b)
+            out[key] = w
+        return out
+
+    def init_random(self, seed: int = 0) -> "CLIPTextModel":
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for name, t in self._params.items():
+            if "layer_norm" in name:
+                t.fill_(1.0 if name.endswith(".weight") else 0.0)
+            elif "embedding" in name:
+                t.copy_((torch.randn(t.shape, generator=g, device=self.device) * 0.5).to(BF16))
+            else:
+                base = name.rsplit(".", 1)[0]
+                k = 1.0 / math.sqrt(self._params[f"{base}.weight"].shape[1])
+                t.copy_(((torch.rand(t.shape, generator=g, device=self.device) * 2 - 1) * k).to(BF16))
+        return self.finalize()
+
+    def load_weights(self, weights, strict: bool = True) -> "CLIPTextModel":
+        items = weights.items() if isinstance(weights, dict) else weights
+        seen = set()
+        for k, w in items:
+            if k not in self._params:
+                if strict and "position_ids" not in k:
+                    raise ValueError(f"Unexpected parameter {k}")
+                continue
+            if tuple(self._params[k].shape) != tuple(w.shape):
+                raise ValueError(f"Shape mismatch for {k}")
+            self._params[k].copy_(w.to(device=self.device, dtype=BF16))
+            seen.add(k)
+        if strict and set(self._params) - seen:
+            raise ValueError(f"Missing parameters: {sorted(set(self._params) - seen)[:5]} ...")
+        return self.finalize()
+
+    def finalize(self) -> "CLIPTextModel":
+        P = self._params
+        self._qk = {}
+        for i in range(self.config.num_layers):
+            a = f"layers.{i}.attention"
+            self._qk[i] = (torch.cat([P[f"{a}.query_proj.weight"], P[f"{a}.key_proj.weight"]], 0).contiguous(),
+                           torch.cat([P[f"{a}.query_proj.bias"], P[f"{a}.key_proj.bias"]], 0).contiguous())
+        return self
+
+    def __call__(self, x: torch.Tensor) -> CLIPOutput:
+        """CLIPTextModel.__call__ (flux/clip.py:127-155): tokens [B,N]."""
+        c, P = self.config, self._params
+        tokens = x.to(dtype=torch.int32)
+        B, N = tokens.shape
+        eos = tokens.argmax(-1)                                   # EOS has the highest id (flux/clip.py:130)
+        tok = tokens.to(self.device).contiguous()
+        D, H = c.model_dims, c.num_heads
+        Np = (N + 7) // 8 * 8                                    # rows padded for the V^T GEMM's N granularity
+        h = ops.embedding(tok, P["token_embedding.weight"], P["position_embedding.weight"])      # [B,N,D]
+        Tpad = (N + 63) // 64 * 64
+        vt = torch.zeros(B, D, Tpad, dtype=BF16, device=self.device)
+        ypad = torch.zeros(B, Np, D, dtype=BF16, device=self.device)
+        o = torch.empty(B, N, D, dtype=BF16, device=self.device)
+        hs = []
+        for i in range(c.num_layers):
+            p = f"layers.{i}"
+            y = ops.layernorm_affine(h, P[f"{p}.layer_norm1.weight"], P[f"{p}.layer_norm1.bias"])
+            qkw, qkb = self._qk[i]
+            qk = ops.linear(y, qkw, qkb)                                                     # [B,N,2D]
+            ypad[:, :N].copy_(y)
+            ops.gemm(make_gemm_desc([dict(A=P[f"{p}.attention.value_proj.weight"].data_ptr(), W=ypad.data_ptr(),
+                                          bias=P[f"{p}.attention.value_proj.bias"].data_ptr(), C=vt.data_ptr(), a_bstride=0,
+                                          w_bstride=Np * D, c_bstride=D * Tpad, M=D)], B, Np, D, D, Tpad, row_bias=True))
+            st = (N * 2 * D, 64, 2 * D)
+            ops.attention_masked(qk, qk[..., D:], vt, o, B, H, N, N, Tpad, st, st, D, 64 ** -0.5, causal=True)
+            h = ops.linear(o, P[f"{p}.attention.out_proj.weight"], P[f"{p}.attention.out_proj.bias"], epi=EPI_GATE_RES, res=h)
+            y = ops.layernorm_affine(h, P[f"{p}.layer_norm2.weight"], P[f"{p}.layer_norm2.bias"])
+            y = ops.linear(y, P[f"{p}.linear1.weight"], P[f"{p}.linear1.bias"], epi=EPI_QUICK_GELU)
+            h = ops.linear(y, P[f"{p}.linear2.weight"], P[f"{p}.linear2.bias"], epi=EPI_GATE_RES, res=h)
+            hs.append(h)
+        last = ops.layernorm_affine(h, P["final_layer_norm.weight"], P["final_layer_norm.bias"])
+        rows = (torch.arange(B, dtype=torch.int32) * N + eos.cpu().to(torch.int32)).to(self.device).contiguous()
+        pooled = ops.embedding(rows, last.view(B * N, D))
+        return CLIPOutput(pooled_output=pooled, last_hidden_state=last, hidden_states=hs)

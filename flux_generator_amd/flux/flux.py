@@ -61,6 +61,10 @@ class FluxPipeline:
 
     def tokenize(self, text):
         t5_tokens = self.t5_tokenizer.encode(text, pad=self.t5_padding)
+        if t5_tokens.shape[1] % 4:      # kernels want T % 4 == 0: only reachable with --no-t5-padding
+            fill = max(getattr(self.t5_tokenizer, "pad_token", 0), 0)
+            extra = 4 - t5_tokens.shape[1] % 4
+            t5_tokens = torch.nn.functional.pad(t5_tokens, (0, extra), value=fill)
         clip_tokens = self.clip_tokenizer.encode(text)
         return t5_tokens, clip_tokens
 

@@ -16,7 +16,10 @@ import torch
 
 from .autoencoder import AutoEncoder, AutoEncoderParams
 from .model import Flux, FluxParams
-from .text import SyntheticCLIP, SyntheticT5, HashTokenizer
+from .clip import CLIP_L, CLIPTextModel, CLIPTextModelConfig
+from .t5 import T5_XXL, T5Config, T5Encoder
+from .text import HashTokenizer
+from .tokenizers import CLIPTokenizer, T5Tokenizer
 
 
 @dataclass
@@ -81,19 +84,65 @@ def load_ae(name: str, hf_download: bool = True, device="cuda", seed: int = 1) -
     return ae
 
 
-# The text encoders and tokenizers are the next row of the scope table;
-# until they land, conditioning tensors of the right shape/dtype come from these stand-ins.
-def load_clip(name: str, device="cuda"):
-    return SyntheticCLIP(dim=configs[name].params.vec_in_dim, device=device)
+# ---- text side.  FLUX_TEXT_DIR may point at a local copy of the hub layout
+# (text_encoder/{config.json,model.safetensors}, text_encoder_2/{config.json,model*.safetensors,
+# model.safetensors.index.json}, tokenizer/{vocab.json,merges.txt}, tokenizer_2/spiece.model); without it the
+# real architectures are random-initialised and the tokenizers fall back to a deterministic hash tokenizer.
+def _text_dir():
+    d = os.getenv("FLUX_TEXT_DIR")
+    return d if d and os.path.isdir(d) else None
 
 
-def load_t5(name: str, device="cuda"):
-    return SyntheticT5(dim=configs[name].params.context_in_dim, device=device)
+def load_clip(name: str, device="cuda", seed: int = 2) -> CLIPTextModel:
+    """flux/utils.py:150-166."""
+    import json
+    d = _text_dir()
+    if d and os.path.exists(os.path.join(d, "text_encoder", "model.safetensors")):
+        with open(os.path.join(d, "text_encoder", "config.json")) as f:
+            clip = CLIPTextModel(CLIPTextModelConfig.from_dict(json.load(f)), device=device)
+        return clip.load_weights(clip.sanitize(_load_safetensors(os.path.join(d, "text_encoder", "model.safetensors"))))
+    warnings.warn("CLIP text encoder: FLUX_TEXT_DIR not set; random-init CLIP-L architecture")
+    return CLIPTextModel(CLIPTextModelConfig(**CLIP_L), device=device).init_random(seed)
+
+
+def load_t5(name: str, device="cuda", seed: int = 3) -> T5Encoder:
+    """flux/utils.py:169-194 (sharded safetensors via model.safetensors.index.json)."""
+    import json
+    d = _text_dir()
+    idx = os.path.join(d, "text_encoder_2", "model.safetensors.index.json") if d else None
+    if idx and os.path.exists(idx):
+        with open(os.path.join(d, "text_encoder_2", "config.json")) as f:
+            t5 = T5Encoder(T5Config.from_dict(json.load(f)), device=device)
+        with open(idx) as f:
+            files = sorted(set(json.load(f)["weight_map"].values()))
+        weights = {}
+        for w in files:
+            weights.update(_load_safetensors(os.path.join(d, "text_encoder_2", w)))
+        return t5.load_weights(t5.sanitize(weights), strict=False)
+    warnings.warn("T5 encoder: FLUX_TEXT_DIR not set; random-init T5-XXL encoder architecture")
+    return T5Encoder(T5Config(**T5_XXL), device=device).init_random(seed)
 
 
 def load_clip_tokenizer(name: str):
-    return HashTokenizer(max_length=77, vocab=49408)
+    """flux/utils.py:197-208."""
+    import json
+    d = _text_dir()
+    vf = os.path.join(d, "tokenizer", "vocab.json") if d else None
+    if vf and os.path.exists(vf):
+        with open(vf, encoding="utf-8") as f:
+            vocab = json.load(f)
+        with open(os.path.join(d, "tokenizer", "merges.txt"), encoding="utf-8") as f:
+            merges = f.read().strip().split("\n")[1: 49152 - 256 - 2 + 1]
+        ranks = {tuple(m.split()): i for i, m in enumerate(merges)}
+        return CLIPTokenizer(ranks, vocab, max_length=77)
+    return HashTokenizer(max_length=77, vocab=49408, pad_with_eos=True)
 
 
 def load_t5_tokenizer(name: str, pad: bool = True):
-    return HashTokenizer(max_length=256 if "schnell" in name else 512, vocab=32128)
+    """flux/utils.py:208-210."""
+    d = _text_dir()
+    mf = os.path.join(d, "tokenizer_2", "spiece.model") if d else None
+    n = 256 if "schnell" in name else 512
+    if mf and os.path.exists(mf):
+        return T5Tokenizer(mf, n)
+    return HashTokenizer(max_length=n, vocab=32128)

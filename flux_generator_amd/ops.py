@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import GemmDesc
 
-EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU = 0, 1, 2, 3, 4, 5
+EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU, EPI_QUICK_GELU = 0, 1, 2, 3, 4, 5, 6
 BF16 = torch.bfloat16
 
 
@@ -308,4 +308,35 @@ def sincos_embed(x: torch.Tensor, sig: torch.Tensor) -> torch.Tensor:
     out = torch.empty(n, 2 * half, dtype=BF16, device=x.device)
     _check(_lib.load().fluxhip_sincos_embed_f32(_p(x.contiguous()), _p(sig.contiguous()), _p(out), n, half, _stream()),
            "fluxhip_sincos_embed_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ text encoders
+def attention_masked(q, k, vt, out, B: int, H: int, Tq: int, Tk: int, Tkpad: int, q_strides, k_strides, ldo: int,
+                     scale: float, bias: Optional[torch.Tensor] = None, causal: bool = False) -> None:
+    _check(_lib.load().fluxhip_attention_masked_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(vt), _p(out), ldo, B, H,
+                                                     Tq, Tk, Tkpad, float(scale), _p(bias), int(causal), _stream()),
+           "fluxhip_attention_masked_bf16")
+
+
+def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16c(x, "x")
+    D = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    _check(_lib.load().fluxhip_rmsnorm_bf16(_p(x), _p(out), x.numel() // D, D, _p(gamma), float(eps), _stream()),
+           "fluxhip_rmsnorm_bf16")
+    return out
+
+
+def embedding(idx: torch.Tensor, table: torch.Tensor, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """idx int32 [..., T] -> bf16 [..., T, D]; pos [>=T, D] is added per position when given."""
+    if idx.dtype != torch.int32 or not idx.is_contiguous():
+        raise FluxHipError("idx must be contiguous int32")
+    _bf16c(table, "table")
+    D = table.shape[1]
+    out = torch.empty(*idx.shape, D, dtype=BF16, device=table.device)
+    T = idx.shape[-1] if pos is not None else 0
+    _check(_lib.load().fluxhip_embedding_bf16(_p(idx), _p(table), _p(pos), _p(out), idx.numel(), D, T, table.shape[0],
+                                              _stream()), "fluxhip_embedding_bf16")
     return out

@@ -32,7 +32,8 @@ enum {
   FLUXHIP_EPI_GATE_RES = 2,   /* C = res + gate * (A W^T + b)        x + mod.gate * proj(...)  */
   FLUXHIP_EPI_SPLIT_GELU = 3, /* cols <  n_split -> C ; cols >= n_split -> gelu_tanh -> C2     */
   FLUXHIP_EPI_SILU = 4,       /* C = silu(A W^T + b)                                            */
-  FLUXHIP_EPI_GEGLU = 5       /* C = res * gelu_erf(A W^T + b)       UNet GEGLU (unet.py:74-78) */
+  FLUXHIP_EPI_GEGLU = 5,      /* C = res * gelu_erf(A W^T + b)       UNet GEGLU (unet.py:74-78) */
+  FLUXHIP_EPI_QUICK_GELU = 6  /* C = v * sigmoid(1.702 v)            CLIP quick_gelu (flux/clip.py:9) */
 };
 
 /* One operand group of a (possibly grouped) GEMM. Two groups share N, K, the epilogue and the
@@ -197,6 +198,25 @@ int fluxhip_pixel_linear_bf16(const void* x, const void* w, const void* bias, vo
 /* nn.SinusoidalPositionalEncoding(cos_first=True): out[n] = [cos(x[n]*sig) | sin(x[n]*sig)], x and
  * sig float32, out bf16 [n][2*half] (unet.py:283-292,301-313,413,419). */
 int fluxhip_sincos_embed_f32(const void* x, const void* sig, void* out, int n, int half, void* stream);
+
+/* ---- text encoders (flux/t5.py, flux/clip.py) ------------------------- */
+
+/* head_dim-64 attention with either an additive per-head bias [H][Tq][Tk] bf16 (T5: relative position
+ * bias passed as the SDPA mask with scale 1.0, flux/t5.py:153-155,220-224; pads are attended) or a
+ * causal mask (CLIP text model, flux/clip.py:91-95,138).  Exactly one of bias / causal must be set. */
+int fluxhip_attention_masked_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K,
+                                  int64_t k_bs, int64_t k_hs, int64_t k_rs, const void* Vt, void* O,
+                                  int ldo, int B, int H, int Tq, int Tk, int Tkpad, float scale,
+                                  const void* bias, int causal, void* stream);
+
+/* nn.RMSNorm(D, eps) with learned scale (flux/t5.py:196-197,216). */
+int fluxhip_rmsnorm_bf16(const void* x, void* out, int64_t rows, int D, const void* gamma, float eps,
+                         void* stream);
+
+/* nn.Embedding: out[i] = table[idx[i]] (+ pos[i % T] when pos != NULL); idx int32 [n], rows of D bf16
+ * (flux/t5.py:229,243; flux/clip.py:83-84,134-135,148). */
+int fluxhip_embedding_bf16(const void* idx, const void* table, const void* pos, void* out, int64_t n,
+                           int D, int T, int V, void* stream);
 
 #ifdef __cplusplus
 }

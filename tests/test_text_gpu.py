@@ -1,0 +1,96 @@
+"""Text encoders on libfluxhip (T5 encoder, CLIP text model) vs the CPU oracle (which is itself pinned
+against `transformers`).  bf16 storage / fp32 accumulate: rel-L2 <= 1.5e-2 on the final hidden states of
+the tiny models (2-3 layers), per-op pieces <= 4e-3."""
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import flux_oracle as O
+from oracle import text_oracle as T
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(*shape, scale=1.0, seed=0, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(dev)
+
+
+def test_masked_attention_modes(dev):
+    from flux_generator_amd import ops
+    B, H, Tn = 2, 3, 100
+    C = H * 64
+    q, k, v = rnd(B, Tn, C, seed=1), rnd(B, Tn, C, seed=2), rnd(B, Tn, C, seed=3)
+    Tpad = 128
+    vt = torch.zeros(B, C, Tpad, dtype=BF, device=dev)
+    vt[..., :Tn] = v.transpose(1, 2)
+    bias = rnd(H, Tn, Tn, seed=4, scale=2.0)
+    o = torch.empty(B, Tn, C, dtype=BF, device=dev)
+    st = (Tn * C, 64, C)
+    sp = lambda t: t.float().cpu().view(B, Tn, H, 64).transpose(1, 2)   # noqa: E731
+    ops.attention_masked(q, k, vt, o, B, H, Tn, Tn, Tpad, st, st, C, 1.0, bias=bias)
+    s = torch.matmul(sp(q), sp(k).transpose(-1, -2)) + bias.float().cpu()[None]
+    ref = torch.matmul(torch.softmax(s, -1), sp(v)).transpose(1, 2).reshape(B, Tn, C)
+    assert rel_l2(o, ref) < 6e-3
+    ops.attention_masked(q, k, vt, o, B, H, Tn, Tn, Tpad, st, st, C, 0.125, causal=True)
+    idx = torch.arange(Tn)
+    s = torch.matmul(sp(q), sp(k).transpose(-1, -2)) * 0.125 + (idx[:, None] < idx[None]).float() * -1e9
+    ref = torch.matmul(torch.softmax(s, -1), sp(v)).transpose(1, 2).reshape(B, Tn, C)
+    assert rel_l2(o, ref) < 6e-3
+    with pytest.raises(ops.FluxHipError):
+        ops.attention_masked(q, k, vt, o, B, H, Tn, Tn, Tpad, st, st, C, 1.0)        # neither bias nor causal
+
+
+def test_rmsnorm_embedding_quickgelu(dev):
+    from flux_generator_amd import ops
+    x, g = rnd(3, 20, 4096, seed=1, scale=2.0), (1 + 0.3 * rnd(4096, seed=2).float()).to(BF)
+    assert rel_l2(ops.rmsnorm(x, g, 1e-6), O.rms_norm(x.float().cpu(), g.float().cpu(), 1e-6)) < 4e-3
+    table, pos = rnd(50, 64, seed=3), rnd(9, 64, seed=4)
+    idx = torch.randint(0, 50, (2, 9), dtype=torch.int32)
+    assert torch.equal(ops.embedding(idx.to(dev), table).cpu(), table.cpu()[idx.long()])
+    want = (table.cpu()[idx.long()].float() + pos.cpu().float()[None]).to(BF)
+    assert torch.equal(ops.embedding(idx.to(dev), table, pos).cpu(), want)
+    n, w, b = rnd(40, 128, seed=5), rnd(256, 128, seed=6, scale=0.1), rnd(256, seed=7)
+    ref = T.quick_gelu(O.linear(n.float().cpu(), w.float().cpu(), b.float().cpu()))
+    assert rel_l2(ops.linear(n, w, b, epi=ops.EPI_QUICK_GELU), ref) < 4e-3
+
+
+def test_t5_encoder_tiny(dev):
+    from flux_generator_amd.flux.t5 import T5Config, T5Encoder
+    kw = dict(vocab_size=200, num_layers=3, num_heads=4, relative_attention_num_buckets=32, d_kv=64, d_model=256,
+              feed_forward_proj="gated-gelu", tie_word_embeddings=False, d_ff=448)
+    ocfg = T.T5Config(**{k: v for k, v in kw.items() if k in T.T5Config.__dataclass_fields__})
+    W = {k: v.to(BF).float() for k, v in O.init_weights(T.t5_weight_shapes(ocfg), seed=0, norm_jitter=0.2).items()}
+    W["wte.weight"] = (torch.randn(200, 256, generator=torch.Generator().manual_seed(1))).to(BF).float()
+    W["encoder.relative_attention_bias.embeddings.weight"] = (torch.randn(32, 4, generator=torch.Generator().manual_seed(2))).to(BF).float()
+    model = T5Encoder(T5Config(**kw), device=dev).load_weights(W)
+    tokens = torch.randint(0, 200, (2, 40), generator=torch.Generator().manual_seed(3))
+    tokens[0, 30:] = 0                                            # pads are attended (no padding mask)
+    got = model(tokens)
+    ref = T.t5_encoder(ocfg, W, tokens)
+    e = rel_l2(got, ref)
+    print(f"t5 tiny rel-L2 {e:.2e}")
+    assert got.shape == (2, 40, 256) and e < 1.5e-2
+    with pytest.raises(ValueError):
+        T5Encoder(T5Config(**{**kw, "d_kv": 32}), device=dev)
+
+
+def test_clip_text_model_tiny(dev):
+    from flux_generator_amd.flux.clip import CLIPTextModel, CLIPTextModelConfig
+    kw = dict(num_layers=2, model_dims=128, num_heads=2, max_length=77, vocab_size=300, hidden_act="quick_gelu")
+    ocfg = T.CLIPTextModelConfig(**kw)
+    W = {k: v.to(BF).float() for k, v in O.init_weights(T.clip_weight_shapes(ocfg), seed=4, norm_jitter=0.2).items()}
+    for k in ("token_embedding.weight", "position_embedding.weight"):
+        W[k] = (torch.randn(W[k].shape, generator=torch.Generator().manual_seed(5)) * 0.5).to(BF).float()
+    model = CLIPTextModel(CLIPTextModelConfig(**kw), device=dev).load_weights(W)
+    tokens = torch.randint(1, 298, (2, 13), generator=torch.Generator().manual_seed(6))
+    tokens[:, 0] = 298
+    tokens[0, 6:] = 299
+    tokens[1, 12] = 299
+    got = model(tokens)
+    ref = T.clip_text_model(ocfg, W, tokens)
+    assert rel_l2(got.last_hidden_state, ref.last_hidden_state) < 1.5e-2
+    assert rel_l2(got.pooled_output, ref.pooled_output) < 1.5e-2
+    assert rel_l2(got.hidden_states[-2], ref.hidden_states[-2]) < 1.5e-2
+    assert got.pooled_output.shape == (2, 128)
