@@ -12,7 +12,7 @@ struct TileCfg {
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
 constexpr TileCfg make_cfg() {
-  return TileCfg{BM, BN, WM * WN * 64, NSTAGE * (BM + BN) * 64 * 2,
+  return TileCfg{BM, BN, WM * WN * 64, (NSTAGE * BM + (PIPE == 3 ? NSTAGE + 1 : NSTAGE) * BN) * 64 * 2,
                  gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE>,
                  gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE>};
 }
@@ -43,6 +43,16 @@ const TileCfg kCfgs[] = {
     make_cfg<128, 192, 2, 2, 3, 1>(),  // 21: 4 waves x (64x96), 120 KiB
     make_cfg<256, 256, 2, 2, 2, 1>(),  // 22: 4 waves x (128x128): one wave per SIMD, 512-register waves
     make_cfg<256, 160, 4, 2, 3, 1>(),  // 23: 3-deep ring, 156 KiB
+    make_cfg<256, 256, 4, 2, 2, 3>(),  // 24: cfg 15 with a 3-deep WEIGHT ring (2 x 32 + 3 x 32 KiB = 160 KiB)
+    make_cfg<256, 224, 4, 2, 2, 3>(),  // 25: cfg 18 "  (2 x 32 + 3 x 28 KiB)
+    make_cfg<256, 192, 4, 2, 2, 3>(),  // 26: cfg 19 "
+    make_cfg<256, 256, 2, 4, 2, 3>(),  // 27: cfg 11 "
+    make_cfg<128, 128, 2, 4, 3, 3>(),  // 28: cfg 16 with a 4-deep weight ring
+    make_cfg<256, 128, 4, 2, 3, 3>(),  // 29: cfg 12 "
+    make_cfg<256, 160, 4, 2, 2, 3>(),  // 30: 256x160, 2 + 3
+    make_cfg<128, 256, 2, 4, 2, 3>(),  // 31: cfg 14, 2 + 3
+    make_cfg<128, 128, 2, 2, 2, 3>(),  // 32: cfg 7, 2 + 3 (80 KiB: 2 blocks/CU)
+    make_cfg<128, 128, 2, 4, 2, 3>(),  // 33: 128x128, 8 waves, 2 + 3
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

@@ -94,7 +94,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   constexpr int BK = 64;
   constexpr int NWAVES = WM * WN;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
   constexpr int APW = BM / 8 / NWAVES;
@@ -181,10 +180,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     }
   }
 
-  auto stage = [&](int kt, int buf) {
-    char* sa = smem + buf * STAGE_BYTES;
-    char* sb = sa + A_BYTES;
-    int koff = kt * BK;                      // K offset (elements) of this step inside a W row
+  // LDS layout: NSA activation slots of A_BYTES, then NSW weight slots of B_BYTES.  The weight ring may be
+  // one slot deeper than the activation ring (PIPE 3): weights are the cold HBM stream (every line is a
+  // compulsory miss for the XCD), activations are re-read by every N-tile and mostly hit L2, and 2 x 32 KiB
+  // + 3 x 32 KiB is exactly the 160 KiB of a CU for the 256 x 256 tile.
+  constexpr int NSA = NSTAGE, NSW = (PIPE == 3) ? NSTAGE + 1 : NSTAGE;
+  constexpr int W_BASE = NSA * A_BYTES;
+  auto stage_a = [&](int kt, int slot) {
+    char* sa = smem + slot * A_BYTES;
     if (AMODE == 0) {
 #pragma unroll
       for (int i = 0; i < APW; ++i)
@@ -192,13 +195,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     } else {
       // K order = channel chunk outer, filter tap inner: the 9 taps of one 64-channel chunk are
       // staged back to back, so their overlapping input rows are still in L1/L2 (a tap-major order
-      // re-streams the whole input tile 9 times through the XCD's L2).  The weight operand follows
-      // with a pure index remap: column = tap*Cin + c0 of the [N][kh*kw*Cin] matrix.
+      // re-streams the whole input tile 9 times through the XCD's L2).
       const int ntap = p.cv.ksize * p.cv.ksize;
       const int cch = kt / ntap;
       const int tap = kt - cch * ntap;
       const int c0 = cch << 6;
-      koff = tap * p.cv.Cin + c0;
       const int dy = (p.cv.ksize == 3) ? tap / 3 : 0;
       const int dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
       const int Hl = p.cv.ups ? p.cv.Hs * 2 : p.cv.Hs;   // logical input grid
@@ -213,6 +214,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
                              : (const char*)p.cv.zero;
         glds16(src, sa + (wave + i * NWAVES) * 1024);
       }
+    }
+  };
+  auto stage_w = [&](int kt, int slot) {
+    char* sb = smem + W_BASE + slot * B_BYTES;
+    int koff = kt * BK;                      // K offset (elements) of this step inside a W row
+    if (AMODE == 1) {                        // conv: weight column = tap*Cin + c0 (pure index remap)
+      const int ntap = p.cv.ksize * p.cv.ksize;
+      const int cch = kt / ntap;
+      koff = (kt - cch * ntap) * p.cv.Cin + (cch << 6);
     }
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
@@ -233,16 +243,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
 
   const int nkt = K / BK;
   constexpr int G = APW + BPW;                       // LDS-DMA instructions per wave per K-step
-  static_assert((NSTAGE - 1) * G <= 63, "vmcnt field");
+  static_assert((NSTAGE - 1) * G + BPW <= 63, "vmcnt field");
 
-  auto load_frags = [&](bf16x8(&af)[MI], bf16x8(&wf)[NJ], int slot, int kk) {
-    const char* sa = smem + slot * STAGE_BYTES + (wm * WTM) * 128 + foff[kk];
-    const char* sb = smem + slot * STAGE_BYTES + A_BYTES + (wn * WTN) * 128 + foff[kk];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 2048);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(sb + j * 2048);
-  };
   auto mma = [&](const bf16x8(&af)[MI], const bf16x8(&wf)[NJ]) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -255,17 +257,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     // simple ring: wait -> barrier -> refill the freed slot -> read fragments -> MFMA
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-      if (s < nkt) stage(s, s);
+      if (s < nkt) { stage_a(s, s); stage_w(s, s); }
     int cur = 0, nxt = NSTAGE - 1;                   // ring slots of step kt and step kt+NSTAGE-1
     for (int kt = 0; kt < nkt; ++kt) {
       if (kt + NSTAGE - 2 < nkt) wait_vmcnt<(NSTAGE - 2) * G>();
       else wait_vmcnt<0>();                          // tail: fewer steps in flight than the ring holds
       __builtin_amdgcn_s_barrier();                  // step kt landed for every wave; slot nxt is free
-      if (kt + NSTAGE - 1 < nkt) stage(kt + NSTAGE - 1, nxt);
+      if (kt + NSTAGE - 1 < nkt) { stage_a(kt + NSTAGE - 1, nxt); stage_w(kt + NSTAGE - 1, nxt); }
+      const char* sa = smem + cur * A_BYTES + (wm * WTM) * 128;
+      const char* sb = smem + W_BASE + cur * B_BYTES + (wn * WTN) * 128;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 af[MI], wf[NJ];
-        load_frags(af, wf, cur, kk);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 2048 + foff[kk]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(sb + j * 2048 + foff[kk]);
         mma(af, wf);
       }
       cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
@@ -281,11 +288,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     // outstanding, i.e. it also waits for the first read of the NEXT cluster (reads retire in order).
     constexpr int NF = (MI + NJ) < 15 ? (MI + NJ) : 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const uint32_t a_rd = lds0 + (wm * WTM) * 128;             // + slot*STAGE_BYTES + foff[kk]
-    const uint32_t b_rd = lds0 + A_BYTES + (wn * WTN) * 128;
-    auto read_frags = [&](bf16x8(&af)[MI], bf16x8(&wf)[NJ], int slot, int kk) {
-      const uint32_t aa = a_rd + slot * STAGE_BYTES + foff[kk];
-      const uint32_t bb = b_rd + slot * STAGE_BYTES + foff[kk];
+    const uint32_t a_rd = lds0 + (wm * WTM) * 128;             // + slotA*A_BYTES + foff[kk]
+    const uint32_t b_rd = lds0 + W_BASE + (wn * WTN) * 128;    // + slotW*B_BYTES + foff[kk]
+    auto read_frags = [&](bf16x8(&af)[MI], bf16x8(&wf)[NJ], int slot_a, int slot_w, int kk) {
+      const uint32_t aa = a_rd + slot_a * A_BYTES + foff[kk];
+      const uint32_t bb = b_rd + slot_w * B_BYTES + foff[kk];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[i]) : "v"(aa), "n"(i * 2048) : "memory");
@@ -293,36 +300,46 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       for (int j = 0; j < NJ; ++j)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(bb), "n"(j * 2048) : "memory");
     };
+    // LDS-DMA issue order (it fixes the vmcnt arithmetic): prologue A0 W0 A1 W1 .. then the extra weight
+    // steps W(NSA)..W(NSW-1); iteration j issues A(j+NSA) then W(j+NSW).  When step kt+1 is needed, the
+    // loads issued after A(kt+1) are W(kt+1-NSA+NSW) plus NSA-2 whole iterations:
+    constexpr int PENDING = BPW * (NSW - NSA) + (NSA - 2) * G;   // == (NSTAGE-2)*G for a uniform ring
 #pragma unroll
-    for (int s = 0; s < NSTAGE; ++s)
-      if (s < nkt) stage(s, s);
-    if (nkt >= NSTAGE) wait_vmcnt<(NSTAGE - 1) * G>();
+    for (int s = 0; s < NSA; ++s)
+      if (s < nkt) { stage_a(s, s); stage_w(s, s); }
+#pragma unroll
+    for (int s = NSA; s < NSW; ++s)
+      if (s < nkt) stage_w(s, s);
+    if (nkt >= NSW) wait_vmcnt<(NSA - 1) * G + (NSW - NSA) * BPW>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     bf16x8 a0[MI], w0[NJ], a1[MI], w1[NJ];
-    read_frags(a0, w0, 0, 0);
-    int cur = 0;
+    read_frags(a0, w0, 0, 0, 0);
+    int ca = 0, cw = 0;                                // ring slots of step kt
     for (int kt = 0; kt < nkt; ++kt) {
-      const int nxt = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-      read_frags(a1, w1, cur, 1);
+      const int na = (ca + 1 == NSA) ? 0 : ca + 1;
+      const int nw = (cw + 1 == NSW) ? 0 : cw + 1;
+      read_frags(a1, w1, ca, cw, 1);
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NF) : "memory");      // a0/w0 landed, a1/w1 in flight
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, w0);
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < nkt) {
-        if (kt + NSTAGE - 1 < nkt) wait_vmcnt<(NSTAGE - 2) * G>();      // step kt+1 landed (mine)
-        else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my reads of slot cur are done
+        if (kt + NSW - 1 < nkt) wait_vmcnt<PENDING>();                // step kt+1 landed (my pieces)
+        else wait_vmcnt<0>();                                          // tail: fewer steps in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my reads of the current slots are done
         __builtin_amdgcn_s_barrier();                                   // ... and everybody else's
-        if (kt + NSTAGE < nkt) stage(kt + NSTAGE, cur);                 // refill the slot just drained
-        read_frags(a0, w0, nxt, 0);
+        if (kt + NSA < nkt) stage_a(kt + NSA, ca);                      // refill the slots just drained
+        if (kt + NSW < nkt) stage_w(kt + NSW, cw);
+        read_frags(a0, w0, na, nw, 0);
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
       mma(a1, w1);
       __builtin_amdgcn_sched_barrier(0);
-      cur = nxt;
+      ca = na;
+      cw = nw;
     }
   }
 
