@@ -10,11 +10,11 @@ struct TileCfg {
   void (*conv)(const GemmParams);
 };
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE, int FLAGS = 0>
 constexpr TileCfg make_cfg() {
-  return TileCfg{BM, BN, WM * WN * 64, (NSTAGE * BM + (PIPE == 3 ? NSTAGE + 1 : NSTAGE) * BN) * 64 * 2,
-                 gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE>,
-                 gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE>};
+  return TileCfg{BM, BN, WM * WN * 64, (NSTAGE * BM + (PIPE >= 3 ? NSTAGE + 1 : NSTAGE) * BN) * 64 * 2,
+                 gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAGS>,
+                 gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE, FLAGS>};
 }
 
 // index 0 is unused ("auto")
@@ -53,41 +53,52 @@ const TileCfg kCfgs[] = {
     make_cfg<128, 256, 2, 4, 2, 3>(),  // 31: cfg 14, 2 + 3
     make_cfg<128, 128, 2, 2, 2, 3>(),  // 32: cfg 7, 2 + 3 (80 KiB: 2 blocks/CU)
     make_cfg<128, 128, 2, 4, 2, 3>(),  // 33: 128x128, 8 waves, 2 + 3
+    make_cfg<256, 256, 4, 2, 2, 1, 1>(),  // 34: cfg 15, phase-timed (diagnostic; see fluxhip_gemm_set_trace)
+    make_cfg<256, 256, 4, 2, 2, 3, 1>(),  // 35: cfg 24, phase-timed
+    make_cfg<256, 256, 4, 2, 2, 4>(),     // 36: cfg 24 with the LDS-DMA pieces spread between the MFMAs
+    make_cfg<256, 224, 4, 2, 2, 4>(),     // 37: cfg 25 "
+    make_cfg<256, 192, 4, 2, 2, 4>(),     // 38: cfg 26 "
+    make_cfg<256, 256, 2, 4, 2, 4>(),     // 39: cfg 27 "
+    make_cfg<128, 128, 2, 4, 3, 4>(),     // 40: cfg 28 "
+    make_cfg<256, 128, 4, 2, 3, 4>(),     // 41: cfg 29 "
+    make_cfg<256, 256, 4, 2, 2, 4, 1>(),  // 42: cfg 36, phase-timed
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 bool g_attr_set[kNumCfgs][2] = {};
+unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
-// Tile selection = argmin of a two-term cost model over the compiled configurations:
-//   rounds(cfg)  = ceil(tiles / (256 CUs x co-resident blocks per CU))        (wave quantisation)
-//   t_tile(cfg)  = tile FLOPs x blocks/CU / chip-rate(cfg)                    (measured, MI355X)
-// chip-rate is the throughput each configuration reaches with every CU busy on cold (HBM-streamed)
-// weights, taken from tools/gemm_tune.py sweeps (profiles/gemm_tune_r01.txt).
-struct Cand { int cfg; int bpc; float rate_tf; };
+// Tile choice: time model fitted to tools/gemm_tune.py sweeps (profiles/r01_gemm_tune_*.txt):
+//   time = ceil(tiles / (256 CUs x blocks/CU)) x (K/64 x t_step + t_fixed)
+// t_step = one K-step of the main loop, t_fixed = prologue fill + epilogue + launch tail of one tile round.
+// With cold (HBM-streamed) weights the fit is within 3-6 % for the one-block-per-CU tiles.
+struct Cand { int cfg; int bpc; float t_step_us; float t_fixed_us; bool conv_ok; };
 const Cand kCands[] = {
-    {15, 1, 1030.f},  // 256x256, 8 waves
-    {18, 1, 1080.f},  // 256x224
-    {19, 1, 1010.f},  // 256x192
-    {12, 1, 900.f},   // 256x128, 3-deep ring
-    {16, 1, 850.f},   // 128x128, 8 waves, 3-deep ring
-    {7, 2, 950.f},    // 128x128, 4 waves, 2 blocks/CU
-    {8, 2, 760.f},    // 128x64
-    {9, 2, 740.f},    // 64x128
-    {4, 4, 480.f},    // 64x64
+    {36, 1, 1.236f, 21.1f, false},   // 256x256, spread LDS-DMA, 2 + 3 ring (implicit-GEMM loader: VGPR spills)
+    {37, 1, 1.221f, 17.8f, true},   // 256x224
+    {38, 1, 1.050f, 16.5f, true},   // 256x192
+    {30, 1, 1.000f, 13.0f, true},   // 256x160
+    {41, 1, 0.790f, 11.2f, true},   // 256x128
+    {31, 1, 0.863f, 10.0f, true},   // 128x256
+    {40, 1, 0.574f, 5.56f, true},   // 128x128, 8 waves
+    {7, 2, 0.903f, 10.2f, true},    // 128x128, 4 waves, 2 blocks/CU
+    {8, 2, 0.847f, 0.30f, true},    // 128x64
+    {9, 2, 0.672f, 2.90f, true},    // 64x128
+    {4, 2, 0.483f, 1.15f, true},    // 64x64
 };
 
-int pick_cfg(const int* group_m, int ngroups, int nbatch, int N) {
+int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool conv = false) {
   float best = 3.4e38f;
   int best_cfg = 4;
   for (const Cand& c : kCands) {
+    if (conv && !c.conv_ok) continue;
     const TileCfg& t = kCfgs[c.cfg];
     long long tiles = 0;
     for (int g = 0; g < ngroups; ++g) tiles += (long long)((group_m[g] + t.bm - 1) / t.bm) * nbatch;
     tiles *= (N + t.bn - 1) / t.bn;
     const long long slots = 256LL * c.bpc;
     const long long rounds = (tiles + slots - 1) / slots;
-    // relative time: rounds x (tile area x blocks/CU / rate); K is common to all candidates
-    const float cost = (float)rounds * (float)(t.bm * t.bn) * (float)c.bpc / c.rate_tf;
+    const float cost = (float)rounds * ((float)(K / 64) * c.t_step_us + c.t_fixed_us);
     if (cost < best) { best = cost; best_cfg = c.cfg; }
   }
   return best_cfg;
@@ -111,6 +122,17 @@ int launch(GemmParams& p, int cfg_idx, bool conv, hipStream_t s) {
       return FLUXHIP_ELAUNCH;
     g_attr_set[cfg_idx][conv] = true;
   }
+  p.trace = g_trace;
+  // LDS-transposed epilogue needs every output-side operand addressable in 16-byte units
+  auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  bool wide = !p.out_f32 && p.N % 8 == 0 && p.ldc % 8 == 0;
+  for (int g = 0; g < p.ngroups && wide; ++g) {
+    const GemmGroup& t = p.g[g];
+    wide = a16(t.C) && t.c_bstride % 8 == 0 && a16(t.res) && a16(t.gate) && t.gate_bstride % 8 == 0;
+  }
+  if (p.epi == EPI_SPLIT_GELU)
+    wide = wide && a16(p.C2) && p.n_split % 8 == 0 && p.ldc2 % 8 == 0 && p.c2_coloff % 8 == 0 && p.c2_bstride % 8 == 0;
+  p.wide_epi = wide;
   dim3 grid(tm_total * p.tiles_n), block(c.threads);
   hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
@@ -161,7 +183,7 @@ extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
   p.out_f32 = d->out_f32;
   if (p.out_f32 && d->epi != FLUXHIP_EPI_BIAS) return FLUXHIP_EINVAL;
   const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
-  int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N);
+  int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K);
   return launch(p, cfg, false, (hipStream_t)stream);
 }
 
@@ -169,7 +191,12 @@ extern "C" int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d) {
   if (!d || d->ngroups < 1 || d->ngroups > 2) return FLUXHIP_EINVAL;
   if (d->tile_cfg > 0) return d->tile_cfg < kNumCfgs ? d->tile_cfg : FLUXHIP_EINVAL;
   const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
-  return pick_cfg(gm, d->ngroups, d->nbatch, d->N);
+  return pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K);
+}
+
+extern "C" int fluxhip_gemm_set_trace(void* buf) {
+  g_trace = (unsigned long long*)buf;
+  return FLUXHIP_OK;
 }
 
 extern "C" int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads) {
@@ -217,6 +244,6 @@ extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bia
   p.addvec = (const bf16_t*)addvec;
   p.addvec_rows = Ho * Wo;
   p.addvec_stride = Cout;
-  int cfg = pick_cfg(&t.M, 1, 1, Cout);
+  int cfg = pick_cfg(&t.M, 1, 1, Cout, p.K, true);
   return launch(p, cfg, true, (hipStream_t)stream);
 }

@@ -80,6 +80,12 @@ struct GemmParams {
   const bf16_t* addvec;  // optional [.., addvec_stride] vector added per group of addvec_rows output rows
   int addvec_rows;
   long long addvec_stride;
+  int wide_epi;          // outputs / residual / gate are 16-byte addressable: LDS-transposed epilogue
+  unsigned long long* trace;  // FLAG_TIMED kernels only: [nblk][nwaves][8] summed segment cycles
+};
+
+enum GemmFlags : int {
+  FLAG_TIMED = 1,     // s_memtime stamps around the phases of the pipelined loop (diagnostic tile configs only)
 };
 
 template <int N>
@@ -89,7 +95,7 @@ DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory
 // opens step kt, so they have NSTAGE-1 compute phases to land; waits are COUNTED (vmcnt(N), never a
 // drain in steady state) and the barrier is a raw s_barrier, because __syncthreads() would drain
 // the in-flight LDS-DMA (cdna guide §5, "Pipelining across barriers").
-template <int BM, int BN, int WM, int WN, int AMODE, int NSTAGE, int PIPE>
+template <int BM, int BN, int WM, int WN, int AMODE, int NSTAGE, int PIPE, int FLAGS = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p) {
   constexpr int BK = 64;
   constexpr int NWAVES = WM * WN;
@@ -103,6 +109,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   static_assert(APW >= 1 && BM % (8 * NWAVES) == 0 && BN % 16 == 0, "tile / wave-count mismatch");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long t_start = 0, rt_start = 0, t_loop0 = 0, t_loop1 = 0;
+  if constexpr ((FLAGS & FLAG_TIMED) != 0) {
+    asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t_start), "=s"(rt_start)::"memory");
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -162,9 +172,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     bsrc[i] = (const char*)(gW + (long long)b * w_bs + (long long)n * K) + lc * 16;
   }
 
-  // conv geometry decode (per staged row), hoisted out of the K loop
-  int cy[APW], cx[APW];
-  const char* cbase[APW];
+  // conv geometry decode (per staged row), hoisted out of the K loop.  Kept in 2 registers per piece
+  // (packed top-left tap coords, image offset in 16-byte units): the 256-wide tiles have no VGPRs to spare.
+  int cyx[APW];
+  uint32_t cimg[APW];
+  const char* const cX = (const char*)p.cv.X + lc * 16;
   if (AMODE == 1) {
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
@@ -174,9 +186,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       int rem = pix - bb * hw;
       int y = rem / p.cv.Wo;
       int x = rem - y * p.cv.Wo;
-      cy[i] = y * p.cv.stride - p.cv.pad;
-      cx[i] = x * p.cv.stride - p.cv.pad;
-      cbase[i] = (const char*)(p.cv.X + (long long)bb * p.cv.Hs * p.cv.Ws * p.cv.Cin) + lc * 16;
+      cyx[i] = ((y * p.cv.stride - p.cv.pad) << 16) | ((x * p.cv.stride - p.cv.pad) & 0xffff);
+      cimg[i] = (uint32_t)(((long long)bb * p.cv.Hs * p.cv.Ws * p.cv.Cin) >> 3);   // Cin % 64 == 0
     }
   }
 
@@ -184,14 +195,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   // one slot deeper than the activation ring (PIPE 3): weights are the cold HBM stream (every line is a
   // compulsory miss for the XCD), activations are re-read by every N-tile and mostly hit L2, and 2 x 32 KiB
   // + 3 x 32 KiB is exactly the 160 KiB of a CU for the 256 x 256 tile.
-  constexpr int NSA = NSTAGE, NSW = (PIPE == 3) ? NSTAGE + 1 : NSTAGE;
+  constexpr int NSA = NSTAGE, NSW = (PIPE >= 3) ? NSTAGE + 1 : NSTAGE;
   constexpr int W_BASE = NSA * A_BYTES;
-  auto stage_a = [&](int kt, int slot) {
+  // [i0, i1) = the subset of this wave's pieces to issue (PIPE 4 spreads them between MFMAs)
+  auto stage_a = [&](int kt, int slot, int i0 = 0, int i1 = 64) {
     char* sa = smem + slot * A_BYTES;
     if (AMODE == 0) {
 #pragma unroll
       for (int i = 0; i < APW; ++i)
-        glds16(asrc[i] + (long long)kt * (BK * 2), sa + (wave + i * NWAVES) * 1024);
+        if (i >= i0 && i < i1) glds16(asrc[i] + (long long)kt * (BK * 2), sa + (wave + i * NWAVES) * 1024);
     } else {
       // K order = channel chunk outer, filter tap inner: the 9 taps of one 64-channel chunk are
       // staged back to back, so their overlapping input rows are still in L1/L2 (a tap-major order
@@ -206,17 +218,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       const int Wl = p.cv.ups ? p.cv.Ws * 2 : p.cv.Ws;
 #pragma unroll
       for (int i = 0; i < APW; ++i) {
-        int yy = cy[i] + dy, xx = cx[i] + dx;
+        if (i < i0 || i >= i1) continue;
+        int yy = (cyx[i] >> 16) + dy, xx = (int)(short)(cyx[i] & 0xffff) + dx;
         bool ok = (yy >= 0) & (yy < Hl) & (xx >= 0) & (xx < Wl);
         int ys = p.cv.ups ? (yy >> 1) : yy;
         int xs = p.cv.ups ? (xx >> 1) : xx;
-        const char* src = ok ? cbase[i] + ((long long)(ys * p.cv.Ws + xs) * p.cv.Cin + c0) * 2
+        uint32_t img = cimg[i];
+        asm volatile("" : "+v"(img));        // keep the 64-bit image base out of loop-invariant hoisting (VGPR budget)
+        const char* src = ok ? cX + (long long)img * 16 + ((long long)(ys * p.cv.Ws + xs) * p.cv.Cin + c0) * 2
                              : (const char*)p.cv.zero;
         glds16(src, sa + (wave + i * NWAVES) * 1024);
       }
     }
   };
-  auto stage_w = [&](int kt, int slot) {
+  auto stage_w = [&](int kt, int slot, int i0 = 0, int i1 = 64) {
     char* sb = smem + W_BASE + slot * B_BYTES;
     int koff = kt * BK;                      // K offset (elements) of this step inside a W row
     if (AMODE == 1) {                        // conv: weight column = tap*Cin + c0 (pure index remap)
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     }
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
-      glds16(bsrc[i] + (long long)koff * 2, sb + min(wave + i * NWAVES, BPIECES - 1) * 1024);
+      if (i >= i0 && i < i1) glds16(bsrc[i] + (long long)koff * 2, sb + min(wave + i * NWAVES, BPIECES - 1) * 1024);
   };
 
   // ---- fragment read offsets (same XOR as the staging source swizzle) ---------
@@ -303,7 +318,95 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     // LDS-DMA issue order (it fixes the vmcnt arithmetic): prologue A0 W0 A1 W1 .. then the extra weight
     // steps W(NSA)..W(NSW-1); iteration j issues A(j+NSA) then W(j+NSW).  When step kt+1 is needed, the
     // loads issued after A(kt+1) are W(kt+1-NSA+NSW) plus NSA-2 whole iterations:
+    constexpr bool TIMED = (FLAGS & FLAG_TIMED) != 0;
     constexpr int PENDING = BPW * (NSW - NSA) + (NSA - 2) * G;   // == (NSTAGE-2)*G for a uniform ring
+    unsigned long long ts[8];
+    uint32_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (TIMED) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_loop0)::"memory");
+#define GEMM_STAMP(i) \
+    if constexpr (TIMED) { asm volatile("s_memtime %0" : "=s"(ts[i])::"memory"); }
+    if constexpr (PIPE == 4) {
+      // Spread LDS-DMA issue.  The CU's texture-address path takes ~16 cycles per 1-KiB piece, so the 64
+      // pieces of a K-step issued back to back after the barrier (PIPE 1/3) hold every wave in the issue
+      // queue for ~700 cycles with the MFMA pipes idle (tools/gemm_phase_trace.py).  Here each piece is
+      // issued between MFMAs: the weight pieces of step kt+NSW-1 inside the first MFMA cluster (their slot
+      // was drained before the previous barrier), the activation pieces of step kt+NSA inside the second.
+      // Issue order: prologue A0 W0 .. A(NSA-1) W(NSA-1) W(NSA) .. W(NSW-2); iteration j: W(j+NSW-1), [wait,
+      // barrier], A(j+NSA).  When step kt+1 is needed, the loads younger than A(kt+1) are NSA-1 weight
+      // steps and NSA-2 activation steps.
+      static_assert(NSW == NSA + 1, "PIPE 4 needs the deeper weight ring");
+      constexpr int PEND4 = (NSA - 1) * BPW + (NSA - 2) * APW;
+      constexpr int NM = MI * NJ;
+      auto mma_spread = [&](const bf16x8(&af)[MI], const bf16x8(&wf)[NJ], auto&& piece, const int np) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            const int idx = i * NJ + j + 1;
+#pragma unroll
+            for (int q = 0; q < np; ++q)
+              if (idx == q * NM / np + NM / (2 * np)) {
+                __builtin_amdgcn_sched_barrier(0);
+                piece(q);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+          }
+      };
+#pragma unroll
+      for (int s = 0; s < NSA; ++s)
+        if (s < nkt) { stage_a(s, s); stage_w(s, s); }
+#pragma unroll
+      for (int s = NSA; s < NSW - 1; ++s)
+        if (s < nkt) stage_w(s, s);
+      if (nkt >= NSW) wait_vmcnt<(NSA - 1) * G + (NSW - 1 - NSA) * BPW>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      bf16x8 a0[MI], w0[NJ], a1[MI], w1[NJ];
+      read_frags(a0, w0, 0, 0, 0);
+      int ca = 0, cw = 0, pw = NSW - 1;                  // slots of step kt (A, W) and of W step kt+NSW-1
+      for (int kt = 0; kt < nkt; ++kt) {
+        const int na = (ca + 1 == NSA) ? 0 : ca + 1;
+        const int nw = (cw + 1 == NSW) ? 0 : cw + 1;
+        const bool more_w = kt + NSW - 1 < nkt, more_a = kt + NSA < nkt;
+        GEMM_STAMP(0)
+        read_frags(a1, w1, ca, cw, 1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TIMED ? (NF > 1 ? NF - 1 : 0) : NF) : "memory");
+        GEMM_STAMP(1)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_spread(a0, w0, [&](int q) { if (more_w) stage_w(kt + NSW - 1, pw, q, q + 1); }, BPW);
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_STAMP(2)
+        if (kt + 1 < nkt) {
+          if (more_w) wait_vmcnt<PEND4>();
+          else wait_vmcnt<0>();
+          GEMM_STAMP(3)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          GEMM_STAMP(4)
+          GEMM_STAMP(5)
+          read_frags(a0, w0, na, nw, 0);
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        GEMM_STAMP(6)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_spread(a1, w1, [&](int q) { if (more_a) stage_a(kt + NSA, ca, q, q + 1); }, APW);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TIMED) {
+          asm volatile("s_memtime %0" : "=s"(ts[7])::"memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+if (kt + 1 < nkt && kt > 0) {
+#pragma unroll
+          for (int i = 0; i < 7; ++i) tsum[i] += (uint32_t)(ts[i + 1] - ts[i]);
+          tsum[7] += 1;
+        }
+        }
+        ca = na;
+        pw = cw;
+        cw = nw;
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < NSA; ++s)
       if (s < nkt) { stage_a(s, s); stage_w(s, s); }
@@ -319,115 +422,216 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     for (int kt = 0; kt < nkt; ++kt) {
       const int na = (ca + 1 == NSA) ? 0 : ca + 1;
       const int nw = (cw + 1 == NSW) ? 0 : cw + 1;
+      GEMM_STAMP(0)
       read_frags(a1, w1, ca, cw, 1);
-      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NF) : "memory");      // a0/w0 landed, a1/w1 in flight
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TIMED ? (NF > 1 ? NF - 1 : 0) : NF) : "memory");   // a0/w0 landed, a1/w1 in flight
+      GEMM_STAMP(1)
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, w0);
       __builtin_amdgcn_sched_barrier(0);
+      GEMM_STAMP(2)
       if (kt + 1 < nkt) {
         if (kt + NSW - 1 < nkt) wait_vmcnt<PENDING>();                // step kt+1 landed (my pieces)
         else wait_vmcnt<0>();                                          // tail: fewer steps in flight
+        GEMM_STAMP(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my reads of the current slots are done
         __builtin_amdgcn_s_barrier();                                   // ... and everybody else's
+        GEMM_STAMP(4)
         if (kt + NSA < nkt) stage_a(kt + NSA, ca);                      // refill the slots just drained
         if (kt + NSW < nkt) stage_w(kt + NSW, cw);
+        GEMM_STAMP(5)
         read_frags(a0, w0, na, nw, 0);
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      GEMM_STAMP(6)
       __builtin_amdgcn_sched_barrier(0);
       mma(a1, w1);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (TIMED) {
+        asm volatile("s_memtime %0" : "=s"(ts[7])::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+if (kt + 1 < nkt && kt > 0) {
+#pragma unroll
+          for (int i = 0; i < 7; ++i) tsum[i] += (uint32_t)(ts[i + 1] - ts[i]);
+          tsum[7] += 1;
+        }
+      }
       ca = na;
       cw = nw;
     }
+    }
+    if constexpr (TIMED) {
+      asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_loop1)::"memory");
+      if (p.trace && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.trace[((long long)bid * NWAVES + wave) * 12 + i] = tsum[i];
+      }
+    }
+#undef GEMM_STAMP
   }
 
-  // ---- epilogue: lane holds C[m][n4 .. n4+3] -----------------------------------
+  // ---- epilogue ------------------------------------------------------------------------------
+  // After the MFMAs a lane holds C[m][n4 .. n4+3] for 16 different rows per wave-instruction: stored
+  // directly that is 32-byte runs, and the 256 x 256 tile's store tail costs ~40 % of its main loop
+  // (tools/gemm_phase_trace.py).  So the tile goes through LDS once (the operand ring is dead by now):
+  // phase A adds bias (+ addvec), rounds to bf16 and writes 8-byte pieces into the wave's own
+  // [WTM][WTN] region; phase B reads 16-byte chunks back row-major, applies the activation / gate /
+  // residual on 8 consecutive columns and stores 16 B per lane = whole 128-byte lines per row.
+  // Every fused epilogue starts from the bf16-rounded (acc + bias), so the LDS round trip is exact.
+  // The direct path remains for float32 outputs and for operands that are not 16-byte aligned.
   const int epi = p.epi;
   const float alpha = p.alpha;
+  constexpr int NCH = WTN / 8;                      // 16-byte chunks per row of the wave's sub-tile
+  const bool wide = p.wide_epi != 0;
+  char* const my_lds = smem + wave * (WTM * WTN * 2);
+  static_assert(BM * BN * 2 <= NSA * A_BYTES + NSW * B_BYTES, "epilogue staging must fit in the operand ring");
+  if (wide) __builtin_amdgcn_s_barrier();           // every wave is done reading the last operand slots
+
+  auto biased = [&](int i, int j, int m, int n4, float (&v)[4]) {
+    if (gBias) {
+      if (p.row_bias) {
+        float bv = bf2f(gBias[m]);
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * WTM + i * 16 + r16;
-    if (m >= Mg) continue;
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha + bv;
+      } else {
+        u32x2 bw = *(const u32x2*)(gBias + n4);
+        v[0] = acc[i][j][0] * alpha + bf_lo(bw[0]);
+        v[1] = acc[i][j][1] * alpha + bf_hi(bw[0]);
+        v[2] = acc[i][j][2] * alpha + bf_lo(bw[1]);
+        v[3] = acc[i][j][3] * alpha + bf_hi(bw[1]);
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
-      if (n4 >= N) continue;
-      float v[4];
-      if (gBias) {
-        if (p.row_bias) {
-          float bv = bf2f(gBias[m]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha + bv;
-        } else {
-          u32x2 bw = *(const u32x2*)(gBias + n4);
-          v[0] = acc[i][j][0] * alpha + bf_lo(bw[0]);
-          v[1] = acc[i][j][1] * alpha + bf_hi(bw[0]);
-          v[2] = acc[i][j][2] * alpha + bf_lo(bw[1]);
-          v[3] = acc[i][j][3] * alpha + bf_hi(bw[1]);
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
+    }
+    if (p.addvec) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
+      u32x2 aw = *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
+      v[0] = rbf(v[0]) + bf_lo(aw[0]);
+      v[1] = rbf(v[1]) + bf_hi(aw[0]);
+      v[2] = rbf(v[2]) + bf_lo(aw[1]);
+      v[3] = rbf(v[3]) + bf_hi(aw[1]);
+    }
+  };
+  // activation / gate / residual on NV consecutive columns of row m starting at column n
+  auto finish = [&](float* v, const int NV, int m, int n, bf16_t*& dst) {
+    dst = gC + (long long)b * c_bs + (long long)m * p.ldc + n;
+    if (epi == EPI_GELU_TANH) {
+      for (int r = 0; r < NV; ++r) v[r] = gelu_tanh_f(v[r]);
+    } else if (epi == EPI_SILU) {
+      for (int r = 0; r < NV; ++r) v[r] = silu_f(v[r]);
+    } else if (epi == EPI_QUICK_GELU) {
+      for (int r = 0; r < NV; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+    } else if (epi == EPI_GATE_RES) {
+      const uint32_t* rp = (const uint32_t*)(gRes + (long long)b * c_bs + (long long)m * p.ldc + n);
+      if (gGate) {
+        const uint32_t* gp = (const uint32_t*)(gGate + (long long)b * gate_bs + n);
+        for (int r = 0; r < NV; r += 2) {
+          const uint32_t rw = rp[r >> 1], gw = gp[r >> 1];
+          v[r] = bf_lo(rw) + rbf(bf_lo(gw) * v[r]);
+          v[r + 1] = bf_hi(rw) + rbf(bf_hi(gw) * v[r + 1]);
         }
       } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
-      }
-      if (p.addvec) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
-        u32x2 aw = *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
-        v[0] = rbf(v[0]) + bf_lo(aw[0]);
-        v[1] = rbf(v[1]) + bf_hi(aw[0]);
-        v[2] = rbf(v[2]) + bf_lo(aw[1]);
-        v[3] = rbf(v[3]) + bf_hi(aw[1]);
-      }
-      if (p.out_f32) {
-        float* fdst = (float*)gC + (long long)b * c_bs + (long long)m * p.ldc + n4;
-        *(f32x4*)fdst = f32x4{v[0], v[1], v[2], v[3]};
-        continue;
-      }
-      bf16_t* dst = gC + (long long)b * c_bs + (long long)m * p.ldc + n4;
-      if (epi == EPI_GELU_TANH) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(rbf(v[r]));
-      } else if (epi == EPI_SILU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(rbf(v[r]));
-      } else if (epi == EPI_QUICK_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = rbf(v[r]);
-          v[r] = t / (1.0f + __expf(-1.702f * t));
-        }
-      } else if (epi == EPI_GATE_RES) {
-        const bf16_t* rp = gRes + (long long)b * c_bs + (long long)m * p.ldc + n4;
-        u32x2 rw = *(const u32x2*)rp;
-        float rr[4] = {bf_lo(rw[0]), bf_hi(rw[0]), bf_lo(rw[1]), bf_hi(rw[1])};
-        if (gGate) {
-          u32x2 gw = *(const u32x2*)(gGate + (long long)b * gate_bs + n4);
-          float gg[4] = {bf_lo(gw[0]), bf_hi(gw[0]), bf_lo(gw[1]), bf_hi(gw[1])};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rr[r] + rbf(gg[r] * rbf(v[r]));
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rr[r] + rbf(v[r]);
-        }
-      } else if (epi == EPI_GEGLU) {   // out = res * gelu_erf(acc + bias)   (y_a * nn.gelu(y_b))
-        const bf16_t* rp = gRes + (long long)b * c_bs + (long long)m * p.ldc + n4;
-        u32x2 rw = *(const u32x2*)rp;
-        v[0] = bf_lo(rw[0]) * rbf(gelu_erf_f(rbf(v[0])));
-        v[1] = bf_hi(rw[0]) * rbf(gelu_erf_f(rbf(v[1])));
-        v[2] = bf_lo(rw[1]) * rbf(gelu_erf_f(rbf(v[2])));
-        v[3] = bf_hi(rw[1]) * rbf(gelu_erf_f(rbf(v[3])));
-      } else if (epi == EPI_SPLIT_GELU) {
-        if (n4 >= p.n_split) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(rbf(v[r]));
-          dst = p.C2 + (long long)b * p.c2_bstride + (long long)m * p.ldc2 +
-                (n4 - p.n_split + p.c2_coloff);
+        for (int r = 0; r < NV; r += 2) {
+          const uint32_t rw = rp[r >> 1];
+          v[r] = bf_lo(rw) + v[r];
+          v[r + 1] = bf_hi(rw) + v[r + 1];
         }
       }
-      u32x2 o;
-      o[0] = pack_bf16x2(v[0], v[1]);
-      o[1] = pack_bf16x2(v[2], v[3]);
-      *(u32x2*)dst = o;
+    } else if (epi == EPI_GEGLU) {   // out = res * gelu_erf(acc + bias)   (y_a * nn.gelu(y_b))
+      const uint32_t* rp = (const uint32_t*)(gRes + (long long)b * c_bs + (long long)m * p.ldc + n);
+      for (int r = 0; r < NV; r += 2) {
+        const uint32_t rw = rp[r >> 1];
+        v[r] = bf_lo(rw) * rbf(gelu_erf_f(v[r]));
+        v[r + 1] = bf_hi(rw) * rbf(gelu_erf_f(v[r + 1]));
+      }
+    } else if (epi == EPI_SPLIT_GELU) {
+      if (n >= p.n_split) {
+        for (int r = 0; r < NV; ++r) v[r] = gelu_tanh_f(v[r]);
+        dst = p.C2 + (long long)b * p.c2_bstride + (long long)m * p.ldc2 + (n - p.n_split + p.c2_coloff);
+      }
+    }
+  };
+
+  // chunk swizzle by row: keeps the 16 rows of a phase-A write and the row pairs of a phase-B read on distinct banks
+  auto cswz = [](int c, int row) { return (NCH & (NCH - 1)) == 0 ? (c ^ (row & (NCH - 1))) : (c + row) % NCH; };
+  if (wide) {
+    // phase A: registers -> LDS
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = i * 16 + r16;
+      const int m = min(m0 + wm * WTM + row, Mg - 1);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n4 = min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4);
+        float v[4];
+        biased(i, j, m, n4, v);
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        const int ch = cswz(j * 2 + (q4 >> 1), row);
+        *(u32x2*)(my_lds + row * (NCH * 16) + ch * 16 + (q4 & 1) * 8) = o;
+      }
+    }
+    // phase B: LDS -> 8 consecutive columns per lane -> global
+    constexpr int NIT = (WTM * NCH + 63) / 64;
+#pragma unroll 4
+    for (int t = 0; t < NIT; ++t) {
+      const int idx = t * 64 + lane;
+      const int row = idx / NCH, c = idx - row * NCH;
+      const int m = m0 + wm * WTM + row, n8 = n0 + wn * WTN + c * 8;
+      if (row >= WTM || m >= Mg || n8 >= N) continue;
+      const u32x4 x = *(const u32x4*)(my_lds + row * (NCH * 16) + cswz(c, row) * 16);
+      bf16_t* dst;
+      u32x4 o = x;
+      if (epi != EPI_BIAS) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[2 * r] = bf_lo(x[r]); v[2 * r + 1] = bf_hi(x[r]); }
+        finish(v, 8, m, n8, dst);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = pack_bf16x2(v[2 * r], v[2 * r + 1]);
+      } else {
+        dst = gC + (long long)b * c_bs + (long long)m * p.ldc + n8;
+      }
+      *(u32x4*)dst = o;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + r16;
+      if (m >= Mg) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
+        if (n4 >= N) continue;
+        float v[4];
+        biased(i, j, m, n4, v);
+        if (p.out_f32) {
+          float* fdst = (float*)gC + (long long)b * c_bs + (long long)m * p.ldc + n4;
+          *(f32x4*)fdst = f32x4{v[0], v[1], v[2], v[3]};
+          continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        bf16_t* dst;
+        finish(v, 4, m, n4, dst);
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)dst = o;
+      }
+    }
+  }
+  if constexpr ((FLAGS & FLAG_TIMED) != 0) {
+    unsigned long long t_end, rt_end;
+    asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t_end), "=s"(rt_end)::"memory");
+    if (p.trace && lane == 0) {
+      unsigned long long* t = p.trace + ((long long)bid * NWAVES + wave) * 12;
+      t[8] = t_end - t_start;        // whole wave, shader cycles
+      t[9] = rt_end - rt_start;      // whole wave, 100 MHz ticks
+      t[10] = t_loop0 - t_start;     // address setup
+      t[11] = t_end - t_loop1;       // epilogue
     }
   }
 }

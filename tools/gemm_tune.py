@@ -65,7 +65,17 @@ for name, (m, n, k, epi) in shapes.items():
             row[c] = round(2.0 * m * n * k / (ms * 1e-3) / 1e12, 1)
         except Exception as ex:  # noqa
             row[c] = f"ERR {ex}"
+    if os.environ.get("TUNE_BLASLT"):        # yardstick only: the vendor library on the same operands
+        for _ in range(3):
+            torch.nn.functional.linear(x, w, b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for it in range(20):
+            torch.nn.functional.linear(x, ws[it % nrot], b)
+        e1.record()
+        torch.cuda.synchronize()
+        row["blaslt"] = round(2.0 * m * n * k / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12, 1)
     res[name] = row
-    best = max((v, c) for c, v in row.items() if isinstance(v, float))
+    best = max((v, c) for c, v in row.items() if isinstance(v, float) and c != "blaslt")
     print(f"{name:12s} M={m} N={n} K={k}: " + " ".join(f"c{c}={v}" for c, v in row.items()) + f"  BEST c{best[1]}={best[0]}", flush=True)
 print(json.dumps(res))
