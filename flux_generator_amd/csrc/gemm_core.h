@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   static_assert(APW >= 1 && BM % (8 * NWAVES) == 0 && BN % 16 == 0, "tile / wave-count mismatch");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long t_start = 0, rt_start = 0, t_loop0 = 0, t_loop1 = 0;
+  unsigned long long t_start = 0, rt_start = 0, t_loop0 = 0, t_loop1 = 0, t_epiA = 0, t_epiB = 0;
   if constexpr ((FLAGS & FLAG_TIMED) != 0) {
     asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t_start), "=s"(rt_start)::"memory");
   }
@@ -465,7 +465,7 @@ if (kt + 1 < nkt && kt > 0) {
       asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_loop1)::"memory");
       if (p.trace && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p.trace[((long long)bid * NWAVES + wave) * 12 + i] = tsum[i];
+        for (int i = 0; i < 8; ++i) p.trace[((long long)bid * NWAVES + wave) * 16 + i] = tsum[i];
       }
     }
 #undef GEMM_STAMP
@@ -487,24 +487,27 @@ if (kt + 1 < nkt && kt > 0) {
   char* const my_lds = smem + wave * (WTM * WTN * 2);
   static_assert(BM * BN * 2 <= NSA * A_BYTES + NSW * B_BYTES, "epilogue staging must fit in the operand ring");
   if (wide) __builtin_amdgcn_s_barrier();           // every wave is done reading the last operand slots
+  unsigned long long t_epi0 = 0;
+  if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_epi0)::"memory");
 
-  auto biased = [&](int i, int j, int m, int n4, float (&v)[4]) {
-    if (gBias) {
-      if (p.row_bias) {
-        float bv = bf2f(gBias[m]);
+  // bias operands are fetched up front (one batch of loads in flight, not one dependent load per MFMA tile)
+  u32x2 bcol[NJ];
+  float brow[MI];
+  {
+    const bool colb = gBias && !p.row_bias, rowb = gBias && p.row_bias;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha + bv;
-      } else {
-        u32x2 bw = *(const u32x2*)(gBias + n4);
-        v[0] = acc[i][j][0] * alpha + bf_lo(bw[0]);
-        v[1] = acc[i][j][1] * alpha + bf_hi(bw[0]);
-        v[2] = acc[i][j][2] * alpha + bf_lo(bw[1]);
-        v[3] = acc[i][j][3] * alpha + bf_hi(bw[1]);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
+    for (int j = 0; j < NJ; ++j) {
+      const int n4 = min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4);
+      bcol[j] = colb ? *(const u32x2*)(gBias + n4) : u32x2{0u, 0u};
     }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) brow[i] = rowb ? bf2f(gBias[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)]) : 0.f;
+  }
+  auto biased = [&](int i, int j, int m, int n4, float (&v)[4]) {
+    v[0] = acc[i][j][0] * alpha + (bf_lo(bcol[j][0]) + brow[i]);
+    v[1] = acc[i][j][1] * alpha + (bf_hi(bcol[j][0]) + brow[i]);
+    v[2] = acc[i][j][2] * alpha + (bf_lo(bcol[j][1]) + brow[i]);
+    v[3] = acc[i][j][3] * alpha + (bf_hi(bcol[j][1]) + brow[i]);
     if (p.addvec) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
       u32x2 aw = *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
       v[0] = rbf(v[0]) + bf_lo(aw[0]);
@@ -573,6 +576,7 @@ if (kt + 1 < nkt && kt > 0) {
         *(u32x2*)(my_lds + row * (NCH * 16) + ch * 16 + (q4 & 1) * 8) = o;
       }
     }
+    if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_epiA)::"memory");
     // phase B: LDS -> 8 consecutive columns per lane -> global
     constexpr int NIT = (WTM * NCH + 63) / 64;
 #pragma unroll 4
@@ -625,13 +629,17 @@ if (kt + 1 < nkt && kt > 0) {
   }
   if constexpr ((FLAGS & FLAG_TIMED) != 0) {
     unsigned long long t_end, rt_end;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_epiB)::"memory");
     asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t_end), "=s"(rt_end)::"memory");
     if (p.trace && lane == 0) {
-      unsigned long long* t = p.trace + ((long long)bid * NWAVES + wave) * 12;
+      unsigned long long* t = p.trace + ((long long)bid * NWAVES + wave) * 16;
       t[8] = t_end - t_start;        // whole wave, shader cycles
       t[9] = rt_end - rt_start;      // whole wave, 100 MHz ticks
       t[10] = t_loop0 - t_start;     // address setup
       t[11] = t_end - t_loop1;       // epilogue
+      t[12] = t_epiA - t_loop1;      // epilogue phase A (barrier, bias, LDS writes)
+      t[13] = t_epiB - t_epiA;       // epilogue phase B issue (LDS reads, fused math, store issue)
+      t[14] = t_epi0 - t_loop1;      // barrier after the main loop (wave skew)
     }
   }
 }

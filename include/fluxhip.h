@@ -80,7 +80,7 @@ int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream);
  * `d` (>= 1), and that configuration's block tile / threads. No device work. */
 int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d);
 int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads);
-/* Diagnostic: device buffer of [blocks][waves][12] u64 that the phase-timed tile configurations fill with
+/* Diagnostic: device buffer of [blocks][waves][16] u64 that the phase-timed tile configurations fill with
  * summed s_memtime deltas per main-loop phase (7 phases, iteration count, whole-wave cycles and 100 MHz ticks, setup and epilogue cycles); NULL disables. */
 int fluxhip_gemm_set_trace(void* buf);
 

@@ -15,14 +15,14 @@ x = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
 ws = [(torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(6)]
 b = torch.randn(N, generator=g, device=dev).to(torch.bfloat16)
 out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-trace = torch.zeros(4096 * 8 * 12, dtype=torch.int64, device=dev)
+trace = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device=dev)
 for i in range(5):
     ops.linear(x, ws[i], b, out=out, tile_cfg=cfg)
 lib.fluxhip_gemm_set_trace(trace.data_ptr())
 ops.linear(x, ws[5], b, out=out, tile_cfg=cfg)
 torch.cuda.synchronize()
 lib.fluxhip_gemm_set_trace(None)
-t = trace.view(-1, 12).cpu().double()
+t = trace.view(-1, 16).cpu().double()
 t = t[t[:, 7] > 0]
 per = t[:, :7] / t[:, 7:8]
 names = ["rd a1 + wait a0", "mma(a0) issue", "vmcnt wait", "lgkm0 + barrier", "DMA issue", "rd a0 issue", "mma(a1) issue"]
@@ -33,3 +33,5 @@ for n, v, lo, hi in zip(names, mean, per.min(0).values, per.max(0).values):
 tot, rt, pro, epi = (float(t[:, i].mean()) for i in (8, 9, 10, 11))
 print(f"  whole wave {tot:.0f} cycles = {rt / 100:.1f} us -> shader clock {tot / rt * 0.1:.2f} GHz; setup {pro:.0f}, "
       f"main loop {tot - pro - epi:.0f}, epilogue {epi:.0f} cycles")
+print(f"  end-of-loop barrier {float(t[:, 14].mean()):.0f};", end="")
+print(f"  epilogue: phase A (incl. barrier) {float(t[:, 12].mean()):.0f}, phase B issue {float(t[:, 13].mean()):.0f}, store drain {float((t[:, 11] - t[:, 12] - t[:, 13]).mean()):.0f} cycles")
