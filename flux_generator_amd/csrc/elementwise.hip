@@ -206,51 +206,79 @@ template <int LPP, int COUT>
 __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
     void* __restrict__ out, int B, int H, int W, int Cout, int out_f32, int clip01) {
-  constexpr int Cin = LPP * 8;
+  // A lane group walks a horizontal run of RUN output pixels: its weight slice (COUT x 9 taps x 8 channels)
+  // lives in registers for the whole run and the 3x3 input window slides, so each new pixel costs 3 loads.
+  constexpr int Cin = LPP * 8, RUN = 16;
   const int tid = threadIdx.x;
   const int c = tid % LPP;
-  const long long pix = (long long)blockIdx.x * (256 / LPP) + tid / LPP;
-  const long long npix = (long long)B * H * W;
-  const long long pp = pix < npix ? pix : npix - 1;
-  const int xx = (int)(pp % W);
-  const int yy = (int)((pp / W) % H);
-  const int b = (int)(pp / ((long long)W * H));
-  float acc[COUT];
-#pragma unroll
-  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int y = yy + ky - 1, xq = xx + kx - 1;
-      const bool ok = (y >= 0) & (y < H) & (xq >= 0) & (xq < W);
-      u32x4 xv = u32x4{0, 0, 0, 0};
-      if (ok) xv = *((const u32x4*)(x + (((long long)b * H + y) * W + xq) * Cin) + c);
-#pragma unroll
-      for (int o = 0; o < COUT; ++o) {
-        const int co = min(o, Cout - 1);
-        u32x4 wv = *((const u32x4*)(w + (((long long)co * 3 + ky) * 3 + kx) * Cin) + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[o] += bf_lo(xv[e]) * bf_lo(wv[e]);
-          acc[o] += bf_hi(xv[e]) * bf_hi(wv[e]);
-        }
-      }
-    }
-  }
+  const int runs_per_row = (W + RUN - 1) / RUN;
+  const long long run = (long long)blockIdx.x * (256 / LPP) + tid / LPP;
+  const long long nruns = (long long)B * H * runs_per_row;
+  const long long rr = run < nruns ? run : nruns - 1;
+  const int x0 = (int)(rr % runs_per_row) * RUN;
+  const int yy = (int)((rr / runs_per_row) % H);
+  const int b = (int)(rr / ((long long)runs_per_row * H));
+  u32x4 wv[COUT][9];
 #pragma unroll
   for (int o = 0; o < COUT; ++o)
 #pragma unroll
-    for (int s = LPP >> 1; s > 0; s >>= 1) acc[o] += __shfl_xor(acc[o], s, 64);
-  if (c == 0 && pix < npix) {
+    for (int t = 0; t < 9; ++t)
+      wv[o][t] = *((const u32x4*)(w + ((long long)min(o, Cout - 1) * 9 + t) * Cin) + c);
+  float bv[COUT];
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) {
-      if (o >= Cout) break;
-      float v = acc[o] + (bias ? bf2f(bias[o]) : 0.f);
-      if (clip01) v = fminf(fmaxf(v + 1.f, 0.f), 2.f) * 0.5f;
-      const long long oi = pix * Cout + o;
-      if (out_f32) ((float*)out)[oi] = v;
-      else ((bf16_t*)out)[oi] = f2bf(v);
+  for (int o = 0; o < COUT; ++o) bv[o] = bias ? bf2f(bias[min(o, Cout - 1)]) : 0.f;
+  auto load_col = [&](int xq, u32x4(&col)[3]) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int y = yy + ky - 1;
+      const bool ok = (y >= 0) & (y < H) & (xq >= 0) & (xq < W);
+      col[ky] = ok ? *((const u32x4*)(x + (((long long)b * H + y) * W + xq) * Cin) + c) : u32x4{0, 0, 0, 0};
+    }
+  };
+  u32x4 win[3][3];                       // win[kx][ky]
+  load_col(x0 - 1, win[0]);
+  load_col(x0, win[1]);
+#pragma unroll 1
+  for (int i = 0; i < RUN; ++i) {
+    const int xx = x0 + i;
+    if (xx >= W) break;
+    load_col(xx + 1, win[2]);
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // (v_dot2c_f32_bf16 would halve the VALU work, but a dependent chain of them returned wrong sums
+            //  on gfx950 under ROCm 7.2 - tools probe, 2026-09 - so this stays on unpack + FMA.)
+            acc[o] += bf_lo(win[kx][ky][e]) * bf_lo(wv[o][ky * 3 + kx][e]);
+            acc[o] += bf_hi(win[kx][ky][e]) * bf_hi(wv[o][ky * 3 + kx][e]);
+          }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o)
+#pragma unroll
+      for (int s = LPP >> 1; s > 0; s >>= 1) acc[o] += __shfl_xor(acc[o], s, 64);
+    if (c == 0 && run < nruns) {
+      const long long pix = ((long long)b * H + yy) * W + xx;
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) {
+        if (o >= Cout) break;
+        float v = acc[o] + bv[o];
+        if (clip01) v = fminf(fmaxf(v + 1.f, 0.f), 2.f) * 0.5f;
+        const long long oi = pix * Cout + o;
+        if (out_f32) ((float*)out)[oi] = v;
+        else ((bf16_t*)out)[oi] = f2bf(v);
+      }
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      win[0][ky] = win[1][ky];
+      win[1][ky] = win[2][ky];
     }
   }
 }
@@ -302,7 +330,7 @@ extern "C" int fluxhip_conv2d_small(const void* x, const void* w, const void* bi
   if (!x || !w || !out || B < 1 || H < 1 || W < 1 || Cin % 8 || Cout < 1) return FLUXHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (Cout <= 4 && (Cin == 128 || Cin == 256 || Cin == 512 || Cin == 64)) {
-    const long long npix = (long long)B * H * W;
+    const long long npix = (long long)B * H * ((W + 15) / 16);   // runs of 16 pixels
 #define FEWOUT(LPP)                                                                                \
   hipLaunchKernelGGL((conv3x3_fewout_kernel<LPP, 4>),                                              \
                      dim3((unsigned)((npix + (256 / LPP) - 1) / (256 / LPP))), dim3(256), 0, s,    \

@@ -1,5 +1,6 @@
 // Host launchers for the bf16 NT GEMM / implicit-GEMM conv (kernel: gemm_core.h).
 #include "../../include/fluxhip.h"
+#include <cstdlib>
 #include "gemm_core.h"
 
 namespace {
@@ -72,26 +73,38 @@ unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 //   time = ceil(tiles / (256 CUs x blocks/CU)) x (K/64 x t_step + t_fixed)
 // t_step = one K-step of the main loop, t_fixed = prologue fill + epilogue + launch tail of one tile round.
 // With cold (HBM-streamed) weights the fit is within 3-6 % for the one-block-per-CU tiles.
-struct Cand { int cfg; int bpc; float t_step_us; float t_fixed_us; bool conv_ok; };
+struct Cand { int cfg; int bpc; float t_step_us; float t_fixed_us; };
 const Cand kCands[] = {
-    {36, 1, 1.236f, 21.1f, false},   // 256x256, spread LDS-DMA, 2 + 3 ring (implicit-GEMM loader: VGPR spills)
-    {37, 1, 1.221f, 17.8f, true},   // 256x224
-    {38, 1, 1.050f, 16.5f, true},   // 256x192
-    {30, 1, 1.000f, 13.0f, true},   // 256x160
-    {41, 1, 0.790f, 11.2f, true},   // 256x128
-    {31, 1, 0.863f, 10.0f, true},   // 128x256
-    {40, 1, 0.574f, 5.56f, true},   // 128x128, 8 waves
-    {7, 2, 0.903f, 10.2f, true},    // 128x128, 4 waves, 2 blocks/CU
-    {8, 2, 0.847f, 0.30f, true},    // 128x64
-    {9, 2, 0.672f, 2.90f, true},    // 64x128
-    {4, 2, 0.483f, 1.15f, true},    // 64x64
+    {36, 1, 1.236f, 21.1f},   // 256x256, spread LDS-DMA, 2 + 3 ring
+    {37, 1, 1.221f, 17.8f},   // 256x224
+    {38, 1, 1.050f, 16.5f},   // 256x192
+    {30, 1, 1.000f, 13.0f},   // 256x160
+    {41, 1, 0.790f, 11.2f},   // 256x128
+    {31, 1, 0.863f, 10.0f},   // 128x256
+    {40, 1, 0.574f, 5.56f},   // 128x128, 8 waves
+    {7, 2, 0.903f, 10.2f},    // 128x128, 4 waves, 2 blocks/CU
+    {8, 2, 0.847f, 0.30f},    // 128x64
+    {9, 2, 0.672f, 2.90f},    // 64x128
+    {4, 2, 0.483f, 1.15f},    // 64x64
 };
 
-int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool conv = false) {
+// The implicit-GEMM (conv) loader has its own table (tools/conv_tune.py): its K-step carries the tap /
+// border address generation, so the plain 2-deep rings win there and the spread-DMA variants lose.
+const Cand kConvCands[] = {
+    {15, 1, 1.930f, 6.0f},    // 256x256
+    {10, 1, 1.110f, 4.8f},    // 256x128
+    {31, 1, 1.106f, 5.4f},    // 128x256
+    {7, 2, 1.155f, 4.0f},     // 128x128, 2 blocks/CU
+    {8, 2, 0.847f, 0.30f},    // 128x64
+    {9, 2, 0.672f, 2.90f},    // 64x128
+    {4, 2, 0.483f, 1.15f},    // 64x64
+};
+
+template <int NC>
+int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbatch, int N, int K) {
   float best = 3.4e38f;
   int best_cfg = 4;
-  for (const Cand& c : kCands) {
-    if (conv && !c.conv_ok) continue;
+  for (const Cand& c : cands) {
     const TileCfg& t = kCfgs[c.cfg];
     long long tiles = 0;
     for (int g = 0; g < ngroups; ++g) tiles += (long long)((group_m[g] + t.bm - 1) / t.bm) * nbatch;
@@ -102,6 +115,11 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
     if (cost < best) { best = cost; best_cfg = c.cfg; }
   }
   return best_cfg;
+}
+
+int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool conv = false) {
+  return conv ? pick_from(kConvCands, group_m, ngroups, nbatch, N, K)
+              : pick_from(kCands, group_m, ngroups, nbatch, N, K);
 }
 
 int launch(GemmParams& p, int cfg_idx, bool conv, hipStream_t s) {
@@ -244,6 +262,7 @@ extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bia
   p.addvec = (const bf16_t*)addvec;
   p.addvec_rows = Ho * Wo;
   p.addvec_stride = Cout;
-  int cfg = pick_cfg(&t.M, 1, 1, Cout, p.K, true);
+  static const int forced = [] { const char* e = getenv("FLUXHIP_CONV_CFG"); return e ? atoi(e) : 0; }();   // tuning knob
+  int cfg = forced > 0 ? forced : pick_cfg(&t.M, 1, 1, Cout, p.K, true);
   return launch(p, cfg, true, (hipStream_t)stream);
 }

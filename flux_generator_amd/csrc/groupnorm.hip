@@ -6,7 +6,7 @@
 // HBM-bound, three launches, deterministic (no atomics):
 //   1. gn_partial : per (batch, pixel chunk) PER-CHANNEL (sum, sumsq) -> ws[b][chunk][C][2]
 //                   (per-channel partials make any C/G work, incl. groups that straddle 16-B chunks)
-//   2. gn_finalize: one wave per (batch, group): fixed-order reduction -> (mean, rstd)
+//   2. gn_finalize: one block per (batch, group): fixed-order reduction -> (mean, rstd)
 //   3. gn_apply   : y = x*a + c per element (a, c fold mean/rstd/gamma/beta), optional SiLU
 // Threads own a fixed 16-byte channel chunk and stride over pixels with 4 loads in flight.
 #include "../../include/fluxhip.h"
@@ -63,22 +63,40 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   }
 }
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(float* __restrict__ ws, int B, int C, int G,
-                                                         int nchunks, float cnt, float eps) {
-  const int i = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(float* __restrict__ ws, int B, int C, int G,
+                                                          int nchunks, float cnt, float eps) {
+  // one block per (batch, group); fixed thread -> item assignment and a fixed reduction tree: deterministic
+  __shared__ float red[2][4];
+  const int i = blockIdx.x, tid = threadIdx.x;
   const int b = i / G, g = i - b * G;
   const int cg = C / G;
   float ts = 0.f, tq = 0.f;
   const int items = nchunks * cg;
-  for (int k = lane; k < items; k += 64) {
-    const int chunk = k / cg, c = g * cg + (k - chunk * cg);
-    const float* o = ws + (((long long)b * nchunks + chunk) * C + c) * 2;
-    ts += o[0];
-    tq += o[1];
+  constexpr int U = 4;
+  for (int k0 = tid; k0 < items; k0 += 256 * U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * 256;
+      const int chunk = k / cg, c = g * cg + (k - chunk * cg);
+      v[u] = k < items ? *(const float2*)(ws + (((long long)b * nchunks + chunk) * C + c) * 2) : float2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ts += v[u].x;
+      tq += v[u].y;
+    }
   }
   ts = wave_sum(ts);
   tq = wave_sum(tq);
-  if (lane == 0) {
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = ts;
+    red[1][tid >> 6] = tq;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    ts = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    tq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const float mean = ts / cnt;
     const float var = fmaxf(tq / cnt - mean * mean, 0.f);
     float* st = ws + ((long long)B * nchunks * C + i) * 2;
@@ -170,7 +188,7 @@ extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, con
   do {                                                                                               \
     hipLaunchKernelGGL((gn_partial_kernel<CB>), grid, block, 0, s, (const bf16_t*)x, (float*)ws, HW, \
                        C, nchunks, ppb);                                                             \
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, s, (float*)ws, B, C, G,         \
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(256), 0, s, (float*)ws, B, C, G,         \
                        nchunks, (float)HW * (float)(C / G), eps);                                    \
     hipLaunchKernelGGL((gn_apply_kernel<CB>), grid, block, 0, s, (const bf16_t*)x, (const float*)ws, \
                        (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)out, HW, C, G, nchunks,   \

@@ -176,11 +176,27 @@ class AutoEncoder:
                        out=out[b].view(N, C), res=x[b].view(N, C))
         return out
 
+    def _conv_in(self, z: torch.Tensor) -> torch.Tensor:
+        """decoder.conv_in (16 -> 512 channels).  16 input channels are below the implicit-GEMM loader's
+        64-channel K-step, so z and the weight are zero-padded to 64 channels (exact: the extra products are 0)
+        and the layer runs on the MFMA path like every other conv."""
+        W = self._params
+        w = W["decoder.conv_in.weight"]
+        cin = w.shape[-1]
+        if cin % 64 == 0:
+            return ops.conv2d(z, w, W["decoder.conv_in.bias"])
+        pad = 64 - cin % 64
+        key = (w.data_ptr(), w._version)
+        if getattr(self, "_conv_in_key", None) != key:
+            self._conv_in_w = torch.nn.functional.pad(w, (0, pad)).contiguous()
+            self._conv_in_key = key
+        return ops.conv2d(torch.nn.functional.pad(z, (0, pad)), self._conv_in_w, W["decoder.conv_in.bias"])
+
     def _decoder(self, z: torch.Tensor, clip01: bool) -> torch.Tensor:
         """Decoder.__call__ (flux/autoencoder.py:271-297). z NHWC bf16 -> float32 NHWC image."""
         A, W = self.params, self._params
         nres = len(A.ch_mult)
-        h = ops.conv2d(z, W["decoder.conv_in.weight"], W["decoder.conv_in.bias"])
+        h = self._conv_in(z)
         h = self._resnet("decoder.mid.block_1", h)
         h = self._attn("decoder.mid.attn_1", h)
         h = self._resnet("decoder.mid.block_2", h)
