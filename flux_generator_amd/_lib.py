@@ -46,6 +46,7 @@ SIGNATURES = {
     "fluxhip_gemm_tile_cfg": (c_int, [C.POINTER(GemmDesc)]),
     "fluxhip_gemm_tile_shape": (c_int, [c_int, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),
     "fluxhip_gemm_set_trace": (c_int, [c_void_p]),
+    "fluxhip_set_workspace": (c_int, [c_void_p, c_int64]),
     "fluxhip_conv2d_bf16": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_void_p]),
     "fluxhip_conv2d_small": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "fluxhip_small_linear_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
@@ -98,4 +99,25 @@ def load() -> C.CDLL:
     if lib.fluxhip_arch() != b"gfx950":
         raise RuntimeError("libfluxhip was not built for gfx950")
     _lib = lib
+    _attach_workspace(lib)
     return lib
+
+
+_workspace = None          # keeps the split-K workspace tensor alive for the life of the process
+WORKSPACE_BYTES = 96 << 20
+
+
+def _attach_workspace(lib) -> None:
+    """Give the library its split-K workspace (include/fluxhip.h: fluxhip_set_workspace): zero-filled device
+    memory owned by this process.  One process drives one GPU, so one buffer is enough; on a
+    host without a GPU (ABI tests) nothing is attached and split-K stays off."""
+    global _workspace
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+        _workspace = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device="cuda")
+    except Exception:       # pragma: no cover - torch missing: the C ABI is still usable without split-K
+        return
+    if lib.fluxhip_set_workspace(_workspace.data_ptr(), WORKSPACE_BYTES) != 0:
+        raise RuntimeError("fluxhip_set_workspace failed")

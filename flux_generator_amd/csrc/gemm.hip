@@ -1,5 +1,6 @@
 // Host launchers for the bf16 NT GEMM / implicit-GEMM conv (kernel: gemm_core.h).
 #include "../../include/fluxhip.h"
+#include <cmath>
 #include <cstdlib>
 #include "gemm_core.h"
 
@@ -100,19 +101,34 @@ const Cand kConvCands[] = {
     {4, 2, 0.483f, 1.15f},    // 64x64
 };
 
+// Split-K workspace (fluxhip_set_workspace): [kSkMaxTiles] int32 hand-off counters, then fp32 partial tiles.
+constexpr int kSkMaxTiles = 16384;
+char* g_ws = nullptr;
+long long g_ws_bytes = 0;
+constexpr float kHopUs = 20.0f, kHopNextUs = 8.0f;   // measured cost of the first / each further hand-off of a chain
+
+// returns cfg | (splits << 8)
 template <int NC>
 int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbatch, int N, int K) {
   float best = 3.4e38f;
   int best_cfg = 4;
+  const int nkt = K / 64;
   for (const Cand& c : cands) {
     const TileCfg& t = kCfgs[c.cfg];
     long long tiles = 0;
     for (int g = 0; g < ngroups; ++g) tiles += (long long)((group_m[g] + t.bm - 1) / t.bm) * nbatch;
     tiles *= (N + t.bn - 1) / t.bn;
     const long long slots = 256LL * c.bpc;
-    const long long rounds = (tiles + slots - 1) / slots;
-    const float cost = (float)rounds * ((float)(K / 64) * c.t_step_us + c.t_fixed_us);
-    if (cost < best) { best = cost; best_cfg = c.cfg; }
+    for (int S = 1; S <= 4; ++S) {
+      if (S > 1) {   // only under-filled grids with a long K loop, and only if the workspace can hold the partials
+        if (c.bpc != 1 || tiles * S > slots || nkt / S < 16 || tiles > kSkMaxTiles) break;
+        if ((long long)kSkMaxTiles * 4 + tiles * t.bm * t.bn * 4LL > g_ws_bytes) break;
+      }
+      const long long rounds = (tiles * S + slots - 1) / slots;
+      const float hop = S > 1 ? kHopUs + (float)(S - 2) * kHopNextUs : 0.f;
+      const float cost = (float)rounds * ((float)((nkt + S - 1) / S) * c.t_step_us + c.t_fixed_us) + hop;
+      if (cost < best) { best = cost; best_cfg = c.cfg | (S << 8); }
+    }
   }
   return best_cfg;
 }
@@ -122,8 +138,11 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
               : pick_from(kCands, group_m, ngroups, nbatch, N, K);
 }
 
-int launch(GemmParams& p, int cfg_idx, bool conv, hipStream_t s) {
-  if (cfg_idx <= 0 || cfg_idx >= kNumCfgs) return FLUXHIP_EINVAL;
+int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s) {
+  const int cfg_idx = cfg_code & 0xff;
+  int splits = cfg_code >> 8;
+  if (splits < 1) splits = 1;
+  if (cfg_idx <= 0 || cfg_idx >= kNumCfgs || splits > 16) return FLUXHIP_EINVAL;
   const TileCfg& c = kCfgs[cfg_idx];
   int tm_total = 0;
   for (int g = 0; g < p.ngroups; ++g) {
@@ -151,7 +170,16 @@ int launch(GemmParams& p, int cfg_idx, bool conv, hipStream_t s) {
   if (p.epi == EPI_SPLIT_GELU)
     wide = wide && a16(p.C2) && p.n_split % 8 == 0 && p.ldc2 % 8 == 0 && p.c2_coloff % 8 == 0 && p.c2_bstride % 8 == 0;
   p.wide_epi = wide;
-  dim3 grid(tm_total * p.tiles_n), block(c.threads);
+  p.splits = splits;
+  if (splits > 1) {
+    const long long tiles = (long long)tm_total * p.tiles_n;
+    if (splits > p.K / 64 || tiles > kSkMaxTiles ||
+        (long long)kSkMaxTiles * 4 + tiles * c.bm * c.bn * 4LL > g_ws_bytes)
+      return FLUXHIP_EINVAL;                        // no (or too small a) split-K workspace
+    p.sk_flag = (int*)g_ws;
+    p.sk_part = (float*)(g_ws + (long long)kSkMaxTiles * 4);
+  }
+  dim3 grid(tm_total * p.tiles_n * splits), block(c.threads);
   hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
@@ -210,6 +238,13 @@ extern "C" int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d) {
   if (d->tile_cfg > 0) return d->tile_cfg < kNumCfgs ? d->tile_cfg : FLUXHIP_EINVAL;
   const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
   return pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K);
+}
+
+extern "C" int fluxhip_set_workspace(void* ws, int64_t bytes) {
+  if (ws && (bytes < (int64_t)kSkMaxTiles * 4 || ((uintptr_t)ws & 255))) return FLUXHIP_EINVAL;
+  g_ws = (char*)ws;
+  g_ws_bytes = ws ? bytes : 0;
+  return FLUXHIP_OK;
 }
 
 extern "C" int fluxhip_gemm_set_trace(void* buf) {

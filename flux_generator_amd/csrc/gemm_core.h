@@ -80,6 +80,9 @@ struct GemmParams {
   const bf16_t* addvec;  // optional [.., addvec_stride] vector added per group of addvec_rows output rows
   int addvec_rows;
   long long addvec_stride;
+  int splits;            // split-K factor S (1 = off): S blocks share one output tile, see the split-K note below
+  float* sk_part;        // [tiles][BM*BN] fp32 partial tiles (caller-provided workspace)
+  int* sk_flag;          // [tiles] hand-off counters, zero between launches
   int wide_epi;          // outputs / residual / gate are 16-byte addressable: LDS-transposed epilogue
   unsigned long long* trace;  // FLAG_TIMED kernels only: [nblk][nwaves][8] summed segment cycles
 };
@@ -120,7 +123,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   const int wm = wave / WN, wn = wave % WN;
 
   // ---- XCD-aware, bijective block -> tile map -------------------------------
-  const int nblk = gridDim.x, bid = blockIdx.x;
+  // Split-K (p.splits = S > 1): S consecutive-in-dispatch blocks of the same XCD own one output tile and
+  // one K range each.  Block s adds the partial tile of block s-1 (fp32, through L2) to its accumulators
+  // and either hands the sum on (s < S-1) or runs the epilogue (s = S-1): a fixed summation order, so the
+  // result is deterministic.  Block s only ever waits for a block with a LOWER block id, which the
+  // dispatcher has already started, so the chain cannot deadlock even when the grid exceeds the chip.
+  const int S = p.splits;
+  int nblk = gridDim.x, bid = blockIdx.x, sidx = 0;
+  if (S > 1) {
+    const int T = nblk / S, full = T >> 3, grp = 8 * S;
+    if (bid < full * grp) {
+      const int g = bid / grp, r = bid - g * grp;
+      sidx = r >> 3;
+      bid = g * 8 + (r & 7);
+    } else {
+      const int r = bid - full * grp, rem = T - full * 8;
+      sidx = r / rem;
+      bid = full * 8 + (r - sidx * rem);
+    }
+    nblk = T;
+  }
   const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int TM = p.tiles_m_total;
@@ -146,6 +168,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   const int m0 = (tm % tpb) * BM;
   const int n0 = tn * BN;
   const int N = p.N, K = p.K;
+  const int nkt_all = K / BK;
+  // K range of this block (even split; skewing the ranges so that the producer finishes early did not
+  // pay: the release fence of the early block slows the L2 for the blocks still in their main loop)
+  const int kbase = (int)((long long)sidx * nkt_all / S);
+  const int nkt = (int)((long long)(sidx + 1) * nkt_all / S) - kbase;
 
   // ---- per-lane staging sources ----------------------------------------------
   const int lr = lane >> 3;             // row inside an 8-row piece
@@ -203,14 +230,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     if (AMODE == 0) {
 #pragma unroll
       for (int i = 0; i < APW; ++i)
-        if (i >= i0 && i < i1) glds16(asrc[i] + (long long)kt * (BK * 2), sa + (wave + i * NWAVES) * 1024);
+        if (i >= i0 && i < i1) glds16(asrc[i] + (long long)(kt + kbase) * (BK * 2), sa + (wave + i * NWAVES) * 1024);
     } else {
       // K order = channel chunk outer, filter tap inner: the 9 taps of one 64-channel chunk are
       // staged back to back, so their overlapping input rows are still in L1/L2 (a tap-major order
       // re-streams the whole input tile 9 times through the XCD's L2).
       const int ntap = p.cv.ksize * p.cv.ksize;
-      const int cch = kt / ntap;
-      const int tap = kt - cch * ntap;
+      const int cch = (kt + kbase) / ntap;
+      const int tap = (kt + kbase) - cch * ntap;
       const int c0 = cch << 6;
       const int dy = (p.cv.ksize == 3) ? tap / 3 : 0;
       const int dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
@@ -233,11 +260,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   };
   auto stage_w = [&](int kt, int slot, int i0 = 0, int i1 = 64) {
     char* sb = smem + W_BASE + slot * B_BYTES;
-    int koff = kt * BK;                      // K offset (elements) of this step inside a W row
+    int koff = (kt + kbase) * BK;            // K offset (elements) of this step inside a W row
     if (AMODE == 1) {                        // conv: weight column = tap*Cin + c0 (pure index remap)
       const int ntap = p.cv.ksize * p.cv.ksize;
-      const int cch = kt / ntap;
-      koff = (kt - cch * ntap) * p.cv.Cin + (cch << 6);
+      const int cch = (kt + kbase) / ntap;
+      koff = ((kt + kbase) - cch * ntap) * p.cv.Cin + (cch << 6);
     }
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
@@ -256,7 +283,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkt = K / BK;
   constexpr int G = APW + BPW;                       // LDS-DMA instructions per wave per K-step
   static_assert((NSTAGE - 1) * G + BPW <= 63, "vmcnt field");
 
@@ -469,6 +495,44 @@ if (kt + 1 < nkt && kt > 0) {
       }
     }
 #undef GEMM_STAMP
+  }
+
+  // ---- split-K hand-off (see the block map above) ---------------------------------------------
+  // Release / acquire at agent scope, executed by ONE lane per block: the release (buffer_wbl2) walks the
+  // whole L2, and one per wave made the hand-off cost ~60 us per launch.  Every wave first waits for its
+  // own stores (vmcnt(0)), the block barrier collects them, then lane 0 fences and moves the counter.
+  if (S > 1) {
+    f32x4* part = (f32x4*)(p.sk_part + (size_t)bid * (BM * BN)) + (size_t)wave * (MI * NJ) * 64 + lane;
+    int* flag = p.sk_flag + bid;
+    if (sidx > 0) {
+      if (tid == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sidx) __builtin_amdgcn_s_sleep(2);
+        __threadfence();                            // acquire (invalidates this CU's L1)
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const f32x4 prev = __builtin_nontemporal_load(part + (i * NJ + j) * 64);
+          acc[i][j] += prev;
+        }
+    }
+    if (sidx < S - 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) part[(i * NJ + j) * 64] = acc[i][j];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores are in L2
+      __syncthreads();                                     // ... and everybody else's
+      if (tid == 0) {
+        __threadfence();                                   // release
+        __hip_atomic_store(flag, sidx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    __syncthreads();                                // every wave has consumed the partial
+    if (tid == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
   }
 
   // ---- epilogue ------------------------------------------------------------------------------

@@ -80,6 +80,14 @@ int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream);
  * `d` (>= 1), and that configuration's block tile / threads. No device work. */
 int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d);
 int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads);
+/* Split-K workspace.  GEMMs whose output has too few tiles to fill the chip (N = 3072 projections at batch 1,
+ * the 64x64 VAE convs) are split along K over 2..4 blocks per tile; the blocks pass an fp32 partial tile through
+ * this buffer in a fixed order (deterministic).  `ws` must be zero-filled, 256-byte aligned device memory that
+ * stays alive and is only used by one stream at a time; the first 64 KiB hold hand-off counters (they return to
+ * zero after every launch).  Without a workspace (or with one too small for a shape) split-K is not used.
+ * A forced tile_cfg may carry the split factor in bits 8+ (cfg | splits << 8); fluxhip_gemm_tile_cfg reports the
+ * same encoding. */
+int fluxhip_set_workspace(void* ws, int64_t bytes);
 /* Diagnostic: device buffer of [blocks][waves][16] u64 that the phase-timed tile configurations fill with
  * summed s_memtime deltas per main-loop phase (7 phases, iteration count, whole-wave cycles and 100 MHz ticks, setup and epilogue cycles); NULL disables. */
 int fluxhip_gemm_set_trace(void* buf);

@@ -26,7 +26,10 @@ shapes = {  # name: (M, N, K, epi)
     "linear2": (M, 3072, 15360, 2),
 }
 only = sys.argv[1:]  # optional list of cfg ids
-cfgs = [int(c) for c in only] if only else list(range(1, ncfg + 1))
+def _code(c):   # "41s2" = tile cfg 41 with split-K 2
+    c = str(c)
+    return int(c.split("s")[0]) | (int(c.split("s")[1]) << 8) if "s" in c else int(c)
+cfgs = [_code(c) for c in only] if only else list(range(1, ncfg + 1))
 res = {}
 for name, (m, n, k, epi) in shapes.items():
     g = torch.Generator(device=dev).manual_seed(0)
@@ -77,5 +80,5 @@ for name, (m, n, k, epi) in shapes.items():
         row["blaslt"] = round(2.0 * m * n * k / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12, 1)
     res[name] = row
     best = max((v, c) for c, v in row.items() if isinstance(v, float) and c != "blaslt")
-    print(f"{name:12s} M={m} N={n} K={k}: " + " ".join(f"c{c}={v}" for c, v in row.items()) + f"  BEST c{best[1]}={best[0]}", flush=True)
+    print(f"{name:12s} M={m} N={n} K={k}: " + " ".join(f"c{c if isinstance(c, str) or c < 256 else str(c & 255) + 's' + str(c >> 8)}={v}" for c, v in row.items()) + f"  BEST c{best[1]}={best[0]}", flush=True)
 print(json.dumps(res))
