@@ -8,8 +8,9 @@ inputs (x_T, txt, vec) already resident in HBM.  Weak scaling: every rank genera
 no data-path collective; the only collective is the timing barrier/max.
 
 The JSON line also carries
-  roofline     — the dominant kernel (the 128x128 bf16 MFMA GEMM tile config): algorithmic FLOPs of
-                 its launches / their HIP-event time, measured live here, vs the dense bf16 MFMA peak;
+  roofline     — the dominant kernel (the bf16 MFMA GEMM tile config with the largest share of a forward):
+                 algorithmic FLOPs of its launches / their HIP-event time, measured live here, vs the dense
+                 bf16 MFMA peak; `traffic` = its HBM bytes per launch from the committed PMC passes;
   cpu_baseline — the CPU oracle (a port; the reference's MLX cannot run here) timed on the host
                  cores on a bounded sample of the same workload, rank 0, N = 1 only.
 """
@@ -66,6 +67,33 @@ def cpu_baseline_sample(T: int, threads: int) -> dict:
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"oracle fp32: 1 DoubleStreamBlock ({t_double:.2f} s) + 2 SingleStreamBlock ({t_single:.2f} s each) "
                       f"at full width, T={T}; extrapolated to 2 steps x (19+38) blocks, VAE decode excluded"}
+
+
+def pmc_traffic(label: str) -> dict:
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (tools/profile_round.sh -> tools/pmc_summary.py; counters cannot be read from inside this process).
+    null when the summary has no row for this kernel."""
+    import csv, re
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.csv")
+    m = re.search(r"cfg(\d+)", label)
+    if not m or not os.path.exists(path):
+        return {"traffic": None}
+    import ctypes
+    from flux_generator_amd import _lib
+    bm, bn, th = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    if _lib.load().fluxhip_gemm_tile_shape(int(m.group(1)), bm, bn, th) != 0:
+        return {"traffic": None}
+    best = None
+    with open(path) as f:
+        for row in csv.DictReader(l for l in f if not l.startswith("#")):
+            t = re.match(r"gemm_nt_kernel<(\d+), (\d+), \d+, \d+, (\d+)", row["kernel"])
+            if t and (int(t.group(1)), int(t.group(2)), int(t.group(3))) == (bm.value, bn.value, 0):
+                if best is None or int(row["launches"]) > int(best["launches"]):
+                    best = row
+    if best is None:
+        return {"traffic": None}
+    return {"traffic": float(best["avg_total_MB"]) * 1e6, "traffic_unit": "HBM+MALL bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": f"profiles/r01_hbm_traffic_pmc.csv: {best['kernel']}"}
 
 
 def main() -> None:
@@ -174,7 +202,8 @@ def main() -> None:
     ach = fl / (ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": dom, "launches_per_forward": n, "avg_launch_ms": ms / n,
                 "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": None}
+                "algorithmic_flop_per_launch": fl / n}
+    roofline.update(pmc_traffic(dom))
     breakdown = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": (round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None)}
                  for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
 

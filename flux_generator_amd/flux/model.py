@@ -357,7 +357,8 @@ class Flux:
                 d = args[0]._obj
                 m_total = sum(d.g[i].M for i in range(d.ngroups)) * d.nbatch
                 flops = 2.0 * m_total * d.N * d.K
-                label = f"fluxhip_gemm_bf16/cfg{lib.fluxhip_gemm_tile_cfg(args[0])}"
+                code = lib.fluxhip_gemm_tile_cfg(args[0])      # tile cfg | split-K factor << 8
+                label = f"fluxhip_gemm_bf16/cfg{code & 255}" + (f"s{code >> 8}" if (code >> 8) > 1 else "")
             elif fn.__name__ == "fluxhip_attention_d128_bf16":
                 Bq, Hq, Tq = args[5], args[6], args[7]
                 flops = 4.0 * Bq * Hq * Tq * Tq * 128
