@@ -253,6 +253,7 @@ extern "C" int fluxhip_gemm_set_trace(void* buf) {
 }
 
 extern "C" int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads) {
+  cfg &= 0xff;                                      // accepts the cfg | splits << 8 code of fluxhip_gemm_tile_cfg
   if (cfg <= 0 || cfg >= kNumCfgs || !bm || !bn || !threads) return FLUXHIP_EINVAL;
   *bm = kCfgs[cfg].bm;
   *bn = kCfgs[cfg].bn;

@@ -50,9 +50,10 @@ def test_tile_picker_is_host_only():
     bm, bn, th = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     for groups, N, K, want in (([1280], 21504, 3072, (256, 224)), ([256, 1024], 9216, 3072, (256, 192)),
                                ([256, 1024], 12288, 3072, (256, 256)), ([1280], 3072, 15360, (128, 128))):
-        c = cfg(groups, N, K)
+        c = cfg(groups, N, K)                   # tile cfg | split-K factor << 8
         assert lib.fluxhip_gemm_tile_shape(c, bm, bn, th) == 0
         assert (bm.value, bn.value) == want, (groups, N, K, c)
+        assert c >> 8 == 1, "no split-K without a workspace (none is attached on a host without a GPU)"
 
 
 def test_product_path_has_no_oracle_or_cpu_fallback():
