@@ -41,8 +41,12 @@ struct AttnParams {
 // MODE 0: plain; MODE 1: additive per-head bias (flux/t5.py:70-116,153-155: scale 1.0, bias passed as
 // the SDPA mask); MODE 2: causal (CLIP text model, flux/clip.py:91-95: key index > query index masked)
 
-template <int HD, int NW, int MODE>
-__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
+// KS = 2: a second set of NW waves takes every other KV tile of the same 128 queries and the two partial
+// (max, sum, O) states are merged through LDS at the end.  At batch 1 the Flux grid is 240 workgroups for
+// 256 CUs: with KS = 1 that is one wave per SIMD, and the MFMA pipe idles through every softmax phase; with
+// KS = 2 each SIMD holds two waves in different phases.
+template <int HD, int NW, int MODE, int KS = 1>
+__global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(const AttnParams p) {
   constexpr int RB = HD * 2;                  // bytes per K row
   constexpr int CPR = RB / 16;                // 16-B chunks per K row
   constexpr int KT_BYTES = KV * RB;           // K tile
@@ -50,8 +54,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   constexpr int STAGE = KT_BYTES + VT_BYTES;
   constexpr int NDS = HD / 16;                // d-steps of S^T
   constexpr int NDB = HD / 32;                // d-blocks of O^T
-  constexpr int KPW = KT_BYTES / 1024 / NW;   // K pieces per wave
-  constexpr int VPW = (HD / 8) / NW;          // V^T pieces per wave
+  constexpr int PPT_K = KT_BYTES / 1024;      // 1-KiB pieces per K tile
+  constexpr int PPT_V = HD / 8;               // ... per V^T tile
+  constexpr int KPW = PPT_K / NW;             // K pieces per wave (KS tiles over NW*KS waves)
+  constexpr int VPW = PPT_V / NW;             // V^T pieces per wave
   constexpr int KROWS = 1024 / RB;            // K rows per 1-KiB piece
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -72,7 +78,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   const bf16_t* Kh = p.K + b * p.k_bs + h * p.k_hs;
   const bf16_t* Vh = p.Vt + (long long)bh * HD * Tkpad;
 
-  const int q0 = qb * (NW * 32) + wave * 32;
+  const int qw = wave % NW, kp = wave / NW;   // query group of this wave, KV-tile parity
+  const int q0 = qb * (NW * 32) + qw * 32;
   const int qrow = min(q0 + ql, Tq - 1);
 
   // Q^T fragments (B operand): lane (q = lane&31, hi) holds d = ds*16 + hi*8 .. +8
@@ -84,31 +91,41 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   // staging sources
   const int kr = lane / CPR, kc = lane % CPR;   // K piece: KROWS rows x CPR chunks
   const int vr = lane >> 3, vc = lane & 7;      // V^T piece: 8 rows x 8 chunks
+  // piece id = wave + i * (NW*KS): tile = id / pieces-per-tile, piece inside the tile = id % pieces-per-tile
   const char* vsrc[VPW];
   int krow[KPW], kchunk[KPW];
 #pragma unroll
   for (int i = 0; i < KPW; ++i) {
-    int row = (wave + i * NW) * KROWS + kr;
-    krow[i] = row;
+    const int id = wave + i * (NW * KS);
+    int row = (id % PPT_K) * KROWS + kr;
+    krow[i] = row + (id / PPT_K) * KV;          // + tile offset in keys
     kchunk[i] = kc ^ (HD == 128 ? (row & 15) : ((row >> 1) & 7));
   }
 #pragma unroll
   for (int i = 0; i < VPW; ++i) {
-    int d = (wave + i * NW) * 8 + vr;
+    const int id = wave + i * (NW * KS);
+    int d = (id % PPT_V) * 8 + vr;
     int lchunk = vc ^ ((d >> 1) & 7);
-    vsrc[i] = (const char*)(Vh + (long long)d * Tkpad) + lchunk * 16;
+    vsrc[i] = (const char*)(Vh + (long long)d * Tkpad) + lchunk * 16 + (id / PPT_V) * (KV * 2);
   }
+  // one stage = KS consecutive KV tiles: [KS][K tile | V^T tile]
   auto stage = [&](int it, int buf) {
-    char* sk = smem + buf * STAGE;
-    char* sv = sk + KT_BYTES;
-    const int key0 = it * KV;
+    char* s0 = smem + buf * (KS * STAGE);
+    const int key0 = it * (KS * KV);
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
+      const int id = wave + i * (NW * KS);
       int key = min(key0 + krow[i], Tk - 1);
-      glds16((const char*)(Kh + (long long)key * p.k_rs) + kchunk[i] * 16, sk + (wave + i * NW) * 1024);
+      glds16((const char*)(Kh + (long long)key * p.k_rs) + kchunk[i] * 16,
+             s0 + (id / PPT_K) * STAGE + (id % PPT_K) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < VPW; ++i) glds16(vsrc[i] + (long long)key0 * 2, sv + (wave + i * NW) * 1024);
+    for (int i = 0; i < VPW; ++i) {
+      const int id = wave + i * (NW * KS);
+      // (a V^T tile past Tkpad is only ever read for fully masked keys; clamp the source inside the row)
+      const long long koff = min((long long)key0 + (id / PPT_V) * KV, (long long)Tkpad - KV) - (id / PPT_V) * KV;
+      glds16(vsrc[i] + koff * 2, s0 + (id / PPT_V) * STAGE + KT_BYTES + (id % PPT_V) * 1024);
+    }
   };
 
   f32x16 oT[NDB];
@@ -136,11 +153,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   wait_vm0();
   __syncthreads();
 
-  for (int it = 0; it < ntiles; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < ntiles) stage(it + 1, cur ^ 1);
-    const char* sk = smem + cur * STAGE;
+  const int nstages = (ntiles + KS - 1) / KS;
+  for (int st = 0; st < nstages; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nstages) stage(st + 1, cur ^ 1);
+    const int it = st * KS + kp;                 // this wave's KV tile
+    const char* sk = smem + cur * (KS * STAGE) + kp * STAGE;
     const char* sv = sk + KT_BYTES;
+    if (KS == 1 || it < ntiles) {
 
     // ---- S^T = K Q^T -------------------------------------------------------
     f32x16 sT[2];
@@ -243,8 +263,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
         }
       }
     }
+    }
     wait_vm0();
     __syncthreads();
+  }
+
+  // ---- KS = 2: fold the odd-tile state into the even-tile wave of the same queries --------------
+  if (KS == 2) {
+    float* mrg = (float*)smem + (size_t)qw * (NDB * 16 + 2) * 64 + lane;   // [qw][reg][lane], after the last barrier
+    if (kp == 1) {
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mrg[(i * 16 + r) * 64] = oT[i][r];
+      mrg[(NDB * 16) * 64] = m_run;
+      mrg[(NDB * 16 + 1) * 64] = l_run;
+    }
+    __syncthreads();
+    if (kp == 1) return;
+    const float m_b = mrg[(NDB * 16) * 64], l_b = mrg[(NDB * 16 + 1) * 64];
+    const float m_new = fmaxf(m_run, m_b);
+    const float fa = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);
+    const float fb = __builtin_amdgcn_exp2f((m_b - m_new) * scale_log2);
+    l_run = l_run * fa + l_b * fb;
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oT[i][r] = oT[i][r] * fa + mrg[(i * 16 + r) * 64] * fb;
   }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l -----------------------------------------
@@ -268,18 +313,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
 
 bool g_attr_done[2][3] = {};
 
-template <int HD, int MODE>
+template <int HD, int MODE, int KS = 1>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
   constexpr int NW = 4;
-  constexpr int lds = 2 * (KV * HD * 2 + HD * KV * 2);
-  auto fn = attn_kernel<HD, NW, MODE>;
-  bool& done = g_attr_done[HD == 128 ? 0 : 1][MODE];
+  constexpr int lds = 2 * KS * (KV * HD * 2 + HD * KV * 2);
+  auto fn = attn_kernel<HD, NW, MODE, KS>;
+  static bool split_done = false;
+  bool& done = KS == 2 ? split_done : g_attr_done[HD == 128 ? 0 : 1][MODE];
   if (!done) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return FLUXHIP_ELAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL(fn, dim3(B * p.H * p.nqb), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL(fn, dim3(B * p.H * p.nqb), dim3(NW * KS * 64), lds, s, p);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 
@@ -298,6 +344,8 @@ extern "C" int fluxhip_attention_d128_bf16(const void* Q, const void* K, const v
   p.ldo = ldo; p.H = H; p.Tq = T; p.Tk = T; p.Tkpad = Tpad;
   p.nqb = (T + 127) / 128;
   p.scale_log2 = scale * 1.4426950408889634f;
+  // fewer workgroups than two per CU: split the KV tiles over a second wave set instead (see attn_kernel)
+  if ((long long)B * H * p.nqb < 384 && T > 2 * KV) return launch_attn<128, 0, 2>(p, B, (hipStream_t)stream);
   return launch_attn<128, 0>(p, B, (hipStream_t)stream);
 }
 

@@ -246,7 +246,7 @@ def test_qk_norm_rope_vt(dev, T, S):
 
 
 # ------------------------------------------------------------------ attention
-@pytest.mark.parametrize("B,H,T", [(1, 2, 128), (2, 3, 200), (1, 1, 1280), (1, 2, 65)])
+@pytest.mark.parametrize("B,H,T", [(1, 2, 128), (2, 3, 200), (1, 1, 1280), (1, 2, 65), (1, 2, 192), (1, 24, 1280), (2, 48, 512)])   # last: 384 workgroups -> single wave set; 192/200/1280: KV tiles split over two wave sets
 def test_attention(dev, B, H, T):
     from flux_generator_amd import ops
     Tpad = (T + 63) // 64 * 64
