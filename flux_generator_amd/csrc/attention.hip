@@ -109,11 +109,13 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
     vsrc[i] = (const char*)(Vh + (long long)d * Tkpad) + lchunk * 16 + (id / PPT_V) * (KV * 2);
   }
   // one stage = KS consecutive KV tiles: [KS][K tile | V^T tile]
-  auto stage = [&](int it, int buf) {
+  // [p0, p1): which of this wave's KPW + VPW pieces to issue (the main loop issues one between MFMAs)
+  auto stage = [&](int it, int buf, int p0 = 0, int p1 = 64) {
     char* s0 = smem + buf * (KS * STAGE);
     const int key0 = it * (KS * KV);
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
+      if (i < p0 || i >= p1) continue;
       const int id = wave + i * (NW * KS);
       int key = min(key0 + krow[i], Tk - 1);
       glds16((const char*)(Kh + (long long)key * p.k_rs) + kchunk[i] * 16,
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
     }
 #pragma unroll
     for (int i = 0; i < VPW; ++i) {
+      if (KPW + i < p0 || KPW + i >= p1) continue;
       const int id = wave + i * (NW * KS);
       // (a V^T tile past Tkpad is only ever read for fully masked keys; clamp the source inside the row)
       const long long koff = min((long long)key0 + (id / PPT_V) * KV, (long long)Tkpad - KV) - (id / PPT_V) * KV;
@@ -142,6 +145,13 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
   // V^T (A operand): row d = db*32 + ql ; bytes: ((kb*4 + j*2 + {0,1}) ^ ((d>>1)&7))*16 + hi*8
   const int v_rowoff = ql * 128 + hi * 8;
   const int v_sw = (ql >> 1) & 7;
+  // LDS byte offsets of the fragments inside a stage (the swizzle is an XOR, so one register per chunk)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t koff[NDS], voff[8];
+#pragma unroll
+  for (int ds = 0; ds < NDS; ++ds) koff[ds] = k_rowoff + (((ds * 2 + hi) ^ k_sw) << 4);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) voff[c] = KT_BYTES + v_rowoff + ((c ^ v_sw) << 4);
 
   int ntiles = (Tk + KV - 1) / KV;
   // causal: keys beyond the workgroup's last query row are all masked (block-uniform trip count:
@@ -156,24 +166,55 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
   const int nstages = (ntiles + KS - 1) / KS;
   for (int st = 0; st < nstages; ++st) {
     const int cur = st & 1;
-    if (st + 1 < nstages) stage(st + 1, cur ^ 1);
+    const bool more = st + 1 < nstages;
+    static_assert(KPW + VPW == NDS, "one LDS-DMA piece per d-step of the S product");
+    if (more && !(KS == 1 || st * KS + kp < ntiles)) stage(st + 1, cur ^ 1);   // idle wave set: no MFMAs to hide behind
     const int it = st * KS + kp;                 // this wave's KV tile
     const char* sk = smem + cur * (KS * STAGE) + kp * STAGE;
     const char* sv = sk + KT_BYTES;
     if (KS == 1 || it < ntiles) {
 
     // ---- S^T = K Q^T -------------------------------------------------------
+    // All K fragments are requested up front (inline asm: hipcc would wait for each read right before
+    // its MFMA) and the two key blocks alternate, so no MFMA waits on the accumulator of the previous one.
+    const uint32_t sbase = lds0 + cur * (KS * STAGE) + kp * STAGE;
+    bf16x8 kf[NDS][2];
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[ds][kb]) : "v"(sbase + koff[ds]), "n"(kb * 32 * RB) : "memory");
     f32x16 sT[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sT[kb][r] = 0.f;
 #pragma unroll
-      for (int ds = 0; ds < NDS; ++ds) {
-        bf16x8 kf = *(const bf16x8*)(sk + kb * 32 * RB + k_rowoff + (((ds * 2 + hi) ^ k_sw) << 4));
-        sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sT[kb], 0, 0, 0);
-      }
+    for (int ds = 0; ds < NDS; ++ds) {
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NDS - 1 - ds) > 15 ? 15 : 2 * (NDS - 1 - ds)) : "memory");
+      __builtin_amdgcn_sched_barrier(0);            // (MFMAs have no memory operands: keep them behind the wait)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds][kb], qf[ds], sT[kb], 0, 0, 0);
+      // next stage's K / V^T pieces, one per d-step: issued back to back after the barrier they cost every
+      // wave ~1000 cycles per stage in the address path with the MFMA pipe idle
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) stage(st + 1, cur ^ 1, ds, ds + 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // V^T fragments of key block 0 travel while the softmax runs (P register pair 8j+e <-> k-slot e)
+    union VFrag { bf16x8 v; u32x2 h[2]; };
+    VFrag vf0[2][NDB], vf1[2][NDB];
+    auto read_v = [&](VFrag(&vf)[2][NDB], int kb) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(vf[j][db].h[0]) : "v"(sbase + voff[kb * 4 + j * 2]), "n"(db * 32 * 128) : "memory");
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(vf[j][db].h[1]) : "v"(sbase + voff[kb * 4 + j * 2 + 1]), "n"(db * 32 * 128) : "memory");
+        }
+    };
+    read_v(vf0, 0);
     const int key0 = it * KV;
     if (MODE == 1) {   // logits = scale * s + bias[h][q][key]; 4 consecutive keys per 8-byte load
 #pragma unroll
@@ -221,7 +262,10 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    if (!__all(m_new == m_run)) {
+    // Lazy rescale: softmax is shift-invariant, so the running reference only has to keep exp2 in range.
+    // It moves when some query's maximum grew by more than 8 in the log2 domain (P <= 2^8 otherwise);
+    // on typical logits that is the first tile or two, instead of nearly every tile.
+    if (__any((m_new - m_run) * scale_log2 > 8.0f)) {
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);
       l_run *= alpha;
 #pragma unroll
@@ -243,26 +287,25 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
     l_run += psum;
 
     // ---- O^T += V^T P^T -------------------------------------------------------
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    auto pv = [&](const VFrag(&vf)[2][NDB], int kb) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        // B operand: k-slot e <-> P reg 8j+e of key block kb
         union { bf16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           pf.u[e] = pack_bf16x2(sT[kb][8 * j + 2 * e], sT[kb][8 * j + 2 * e + 1]);
-        const int c1 = kb * 4 + j * 2;
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-          const char* base = sv + db * 32 * 128 + v_rowoff;
-          union { bf16x8 v; u32x2 h[2]; } vf;
-          vf.h[0] = *(const u32x2*)(base + (((c1) ^ v_sw) << 4));
-          vf.h[1] = *(const u32x2*)(base + (((c1 + 1) ^ v_sw) << 4));
-          oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oT[db], 0, 0, 0);
-        }
+        for (int db = 0; db < NDB; ++db)
+          oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j][db].v, pf.v, oT[db], 0, 0, 0);
       }
-    }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    read_v(vf1, 1);                                   // lands under the MFMAs of key block 0
+    pv(vf0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    pv(vf1, 1);
     }
     wait_vm0();
     __syncthreads();
