@@ -104,6 +104,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--denoise-steps", type=int, default=2)
+    ap.add_argument("--model", default="flux-schnell", help="flux-schnell (headline) or flux-dev (BASELINE.json configs[2])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="run a few steps for rocprofv3, print nothing else")
@@ -125,7 +126,7 @@ def main() -> None:
     from flux_generator_amd.flux.flux import FluxPipeline
     import warnings
     warnings.simplefilter("ignore")
-    pipe = FluxPipeline("flux-schnell", device=str(dev), use_graph=not args.no_graph)
+    pipe = FluxPipeline(args.model, device=str(dev), use_graph=not args.no_graph)
 
     B = args.batch
     lat = args.image_size // 8
@@ -211,11 +212,11 @@ def main() -> None:
         total_images = world * args.steps * B
         fwd_tflop = flux_forward_flops(L, S) / 1e12
         out = {
-            "metric": "images/sec, Flux-schnell 512x512 2-step (denoise-step ms in config)",
+            "metric": f"images/sec, {args.model.replace('flux-', 'Flux-')} {args.image_size}x{args.image_size} {args.denoise_steps}-step (denoise-step ms in config)",
             "value": total_images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Flux-schnell {args.image_size}x{args.image_size} {args.denoise_steps}-step, "
+            "config": {"workload": f"{args.model.replace('flux-', 'Flux-')} {args.image_size}x{args.image_size} {args.denoise_steps}-step, "
                                    f"batch {B}/GPU, random-init weights, synthetic x_T/txt/vec resident in HBM; "
                                    "per step: 2 x (Flux forward + Euler) + VAE decode",
                        "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",

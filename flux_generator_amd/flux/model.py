@@ -16,6 +16,7 @@ guidance)`` contract and ValueErrors as the reference (flux/model.py:35-136); th
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from dataclasses import dataclass
 from typing import Dict, Iterable, List, Optional, Tuple, Union
@@ -62,6 +63,7 @@ class Flux:
         self.hidden_size = params.hidden_size
         self.num_heads = params.num_heads
         self.device = torch.device(device)
+        self._side = None            # side stream of the launch plan (modulation GEMV under the first blocks)
         if self.device.type != "cuda":
             raise FluxHipError("Flux needs a HIP device: there is no CPU fallback for the denoise path")
         _lib.load()
@@ -247,7 +249,17 @@ class Flux:
         small(ptr["in_y"], "vector_in.in_layer", ptr["h1"], P.vec_in_dim, D, 0, 0)
         small(ptr["h1"], "vector_in.out_layer", ptr["vec"], D, D, 1, 1)
         # every Modulation.lin(silu(vec)) of the step in one launch            flux/layers.py:136-137
-        call(lib.fluxhip_small_linear_bf16, ptr["vec"], self.mod_w.data_ptr(), self.mod_b.data_ptr(), mp, B, NM, D, 1, 0)
+        # (6.5 GB of weights at batch 1: pure HBM streaming, ~0.95 ms.)  The rows of the first JOIN_AT double blocks
+        # are computed in line; the rest runs on a side stream underneath the first blocks' MFMA-bound GEMMs and is
+        # joined before block JOIN_AT reads its rows.  Only for B == 1: a row range of the [B, NM] table is not a
+        # dense [B, n] block for the GEMV's output addressing at larger batch, where it also matters less.
+        JOIN_AT = int(os.environ.get("FLUXHIP_MOD_JOIN", "3"))
+        split_rows = self.mod_off[f"double_blocks.{JOIN_AT}.img_mod.lin"] if (B == 1 and P.depth > JOIN_AT) else NM
+        call(lib.fluxhip_small_linear_bf16, ptr["vec"], self.mod_w.data_ptr(), self.mod_b.data_ptr(), mp, B, split_rows, D, 1, 0)
+        if split_rows < NM:
+            plan.append(("side", (lib.fluxhip_small_linear_bf16,
+                                  (ptr["vec"], self.mod_w.data_ptr() + split_rows * D * e, self.mod_b.data_ptr() + split_rows * e,
+                                   mp + split_rows * e, B, NM - split_rows, D, 1, 0))))
         # pe = EmbedND(ids)                                                    flux/model.py:123-124
         call(lib.fluxhip_rope_table_bf16, ptr["in_ids"], ptr["rope"], B * T, 3, P.axes_dim[0], P.axes_dim[1],
              P.axes_dim[2], float(P.theta))
@@ -275,6 +287,8 @@ class Flux:
 
         for i in range(P.depth):                                              # flux/layers.py:181-231
             p = f"double_blocks.{i}"
+            if i == JOIN_AT and split_rows < NM:
+                plan.append(("join", ()))
             io, to = self.mod_off[f"{p}.img_mod.lin"], self.mod_off[f"{p}.txt_mod.lin"]
             call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, S, T * D, T * D,
                  mp + to * e, mp + (to + D) * e, mp + io * e, mp + (io + D) * e, NM, 1e-6)
@@ -350,8 +364,10 @@ class Flux:
         stream = torch.cuda.current_stream()
         recs = []
         for fn, args in ws["plan"]:
-            if fn == "keepalive":
+            if fn in ("keepalive", "join"):
                 continue
+            if fn == "side":        # timed in line here (the graph runs it on the side stream)
+                fn, args = args
             label, flops = fn.__name__, 0.0
             if fn.__name__ == "fluxhip_gemm_bf16":
                 d = args[0]._obj
@@ -373,10 +389,21 @@ class Flux:
         return [(l, e0.elapsed_time(e1), f) for l, e0, e1, f in recs]
 
     def run_plan(self, ws: dict) -> None:
-        stream = torch.cuda.current_stream().cuda_stream
+        cur = torch.cuda.current_stream()
+        stream = cur.cuda_stream
         for fn, args in ws["plan"]:
             if fn == "keepalive":
                 continue
-            rc = fn(*args, stream)
+            if fn == "side":        # fork: launch on the side stream, ordered after everything enqueued so far
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(cur)
+                fn, args = args
+                rc = fn(*args, self._side.cuda_stream)
+            elif fn == "join":
+                cur.wait_stream(self._side)
+                continue
+            else:
+                rc = fn(*args, stream)
             if rc != 0:
                 raise FluxHipError(f"{fn.__name__} failed with code {rc}")
