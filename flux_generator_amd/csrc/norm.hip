@@ -11,13 +11,13 @@ namespace {
 // One wave per token row; NCH = ceil(D / 512) 16-byte chunks per lane kept in registers.
 // ---------------------------------------------------------------------------------------------
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_modulate_kernel(
+__global__ __launch_bounds__(512) void ln_modulate_kernel(
     const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int Tr, int D, int S,
     long long x_bstride, long long out_bstride, const bf16_t* __restrict__ shift_txt,
     const bf16_t* __restrict__ scale_txt, const bf16_t* __restrict__ shift_img,
     const bf16_t* __restrict__ scale_img, long long mod_bstride, float eps) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= (long long)B * Tr) return;
   const int b = (int)(row / Tr);
   const int t = (int)(row - (long long)b * Tr);
@@ -30,6 +30,14 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
 
   float v[NCH][8];
   float sum = 0.f;
+  // shift / scale do not depend on the statistics: request them with the row so one latency covers both
+  u32x4 shw[NCH], scw[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = min(lane + i * 64, nchunk - 1);
+    shw[i] = *((const u32x4*)sh + c);
+    scw[i] = *((const u32x4*)sc + c);
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int c = lane + i * 64;
@@ -65,16 +73,14 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
   for (int i = 0; i < NCH; ++i) {
     int c = lane + i * 64;
     if (c < nchunk) {
-      u32x4 shw = *((const u32x4*)sh + c);
-      u32x4 scw = *((const u32x4*)sc + c);
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // reference op boundaries: LN -> bf16, (1+scale) -> bf16, product -> bf16, + shift -> bf16
         float n0 = rbf((v[i][2 * e] - mean) * rstd);
         float n1 = rbf((v[i][2 * e + 1] - mean) * rstd);
-        float y0 = rbf(rbf(1.f + bf_lo(scw[e])) * n0) + bf_lo(shw[e]);
-        float y1 = rbf(rbf(1.f + bf_hi(scw[e])) * n1) + bf_hi(shw[e]);
+        float y0 = rbf(rbf(1.f + bf_lo(scw[i][e])) * n0) + bf_lo(shw[i][e]);
+        float y1 = rbf(rbf(1.f + bf_hi(scw[i][e])) * n1) + bf_hi(shw[i][e]);
         o[e] = pack_bf16x2(y0, y1);
       }
       *((u32x4*)orow + c) = o;
@@ -185,7 +191,10 @@ extern "C" int fluxhip_ln_modulate_bf16(const void* x, void* out, int B, int Tr,
     return FLUXHIP_EINVAL;
   if (S > 0 && (!shift_txt || !scale_txt)) return FLUXHIP_EINVAL;
   const long long rows = (long long)B * Tr;
-  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  // one wave per row; waves per workgroup chosen so that the grid is ~one workgroup per CU (1280 rows -> 256 x 5)
+  int wpb = (int)((rows + 255) / 256);
+  wpb = wpb < 1 ? 1 : wpb > 8 ? 8 : wpb;
+  dim3 grid((unsigned)((rows + wpb - 1) / wpb)), block(wpb * 64);
   hipStream_t s = (hipStream_t)stream;
   const int nch = (D + 511) / 512;
 #define LN_LAUNCH(NCH)                                                                            \
