@@ -104,3 +104,63 @@ def test_full_width_blocks(dev):
     ref = O.flux_forward(OP, W, img.float(), img_ids, txt.float(), txt_ids, t, vec.float())
     got = model(img.to(dev), img_ids.to(dev), txt.to(dev), txt_ids.to(dev), t.to(dev), vec.to(dev))
     assert rel_l2(got, ref) < 1e-2
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json configs[1] at FULL size (19 double + 38 single blocks, hidden 3072, T = 256 + 1024 tokens,
+    11.9 B random-init parameters).  The CPU oracle cannot finish a full-size forward in seconds, so this checks
+    size-independent properties through the same C-ABI launch plan the benchmark runs:
+      1. repeatability bit for bit (covers the split-K hand-off chain and the side-stream modulation GEMV);
+      2. hipGraph replay == eager plan;
+      3. batch consistency: the same image twice in one batch == the single image (tile picks differ with M, so
+         to bf16 tolerance);
+      4. zero-gate identity: with every block's Modulation.lin zeroed all gates are 0, the residual stream passes
+         through all 57 blocks unchanged, and pred == final_layer(img_in(img)) - which the oracle does compute at
+         full size."""
+    from flux_generator_amd.flux.utils import configs
+    from flux_generator_amd.flux.model import Flux
+    P = configs["flux-schnell"].params
+    model = Flux(P, device=dev).init_random(3)
+    OP = O.FluxParams(in_channels=P.in_channels, vec_in_dim=P.vec_in_dim, context_in_dim=P.context_in_dim,
+                      hidden_size=P.hidden_size, mlp_ratio=P.mlp_ratio, num_heads=P.num_heads, depth=P.depth,
+                      depth_single_blocks=P.depth_single_blocks, axes_dim=P.axes_dim, theta=P.theta, qkv_bias=True,
+                      guidance_embed=False)
+    img, img_ids, txt, txt_ids, vec = make_inputs(OP, 1, 256, 64, 64, seed=2)
+    t = torch.full((1,), 0.75, dtype=BF)
+    args = [a.to(dev) for a in (img, img_ids, txt, txt_ids, t, vec)]
+    a = model(*args)
+    b = model(*args)
+    assert bool(torch.isfinite(a).all())
+    assert torch.equal(a, b), "full-size forward is not repeatable"
+
+    # 2. graph replay of the same plan
+    ws = model._workspace(1, 256, 1024)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model.run_plan(ws)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g):
+        model.run_plan(ws)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ws["pred"], a), "hipGraph replay differs from the eager plan"
+
+    # 3. batch consistency
+    args2 = [torch.cat([x, x], dim=0) for x in args]
+    c = model(*args2)
+    assert torch.equal(c[0], c[1])
+    assert rel_l2(c[0], a[0].float().cpu()) < 1e-2
+
+    # 4. zero-gate identity against the oracle
+    keep = model.mod_off["final_layer.adaLN_modulation.layers.1"]
+    model.mod_w[:keep].zero_()
+    model.mod_b[:keep].zero_()
+    got = model(*args)
+    Wc = {k: v.float().cpu() for k, v in model.parameters().items()
+          if k.startswith(("img_in.", "time_in.", "vector_in.", "final_layer."))}
+    x = O.linear(img.float(), Wc["img_in.weight"], Wc["img_in.bias"])
+    v = O.mlp_embedder(Wc, "time_in", O.timestep_embedding(t, 256).float()) + O.mlp_embedder(Wc, "vector_in", vec.float())
+    ref = O.last_layer(Wc, x, v)
+    assert rel_l2(got, ref) < 1e-2
