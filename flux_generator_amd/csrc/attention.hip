@@ -22,6 +22,7 @@
 //    place; V^T ([B][H*HD][Tkpad], zero padded keys) comes from fluxhip_qk_norm_rope_bf16 (Flux) or
 //    directly from the value-projection GEMM written transposed (UNet).
 #include "../../include/fluxhip.h"
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -388,6 +389,8 @@ extern "C" int fluxhip_attention_d128_bf16(const void* Q, const void* K, const v
   p.nqb = (T + 127) / 128;
   p.scale_log2 = scale * 1.4426950408889634f;
   // fewer workgroups than two per CU: split the KV tiles over a second wave set instead (see attn_kernel)
+  static const int variant = [] { const char* e = getenv("FLUXHIP_ATTN"); return e ? atoi(e) : 0; }();   // tuning knob (tools/attn_bench.py)
+  if (variant == 2) return launch_attn<128, 0>(p, B, (hipStream_t)stream);
   if ((long long)B * H * p.nqb < 384 && T > 2 * KV) return launch_attn<128, 0, 2>(p, B, (hipStream_t)stream);
   return launch_attn<128, 0>(p, B, (hipStream_t)stream);
 }
