@@ -507,7 +507,7 @@ if (kt + 1 < nkt && kt > 0) {
     if (sidx > 0) {
       if (tid == 0) {
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sidx) __builtin_amdgcn_s_sleep(2);
-        __threadfence();                            // acquire (invalidates this CU's L1)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv only: drop this CU's stale L1 lines
       }
       __syncthreads();
 #pragma unroll
@@ -526,7 +526,7 @@ if (kt + 1 < nkt && kt > 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores are in L2
       __syncthreads();                                     // ... and everybody else's
       if (tid == 0) {
-        __threadfence();                                   // release
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 only: the partial leaves this XCD's L2
         __hip_atomic_store(flag, sidx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       return;
