@@ -178,7 +178,8 @@ class UNetModel:
         return self.finalize()
 
     def finalize(self) -> "UNetModel":
-        """Derived weight layouts: [q;k] projection fused, conv_in input channels zero-padded to 8."""
+        """Derived weight layouts: [q;k] projection fused, conv_in input channels zero-padded to 64 (one K-step of
+        the implicit-GEMM loader, so the layer runs on the MFMA path; the extra products are exact zeros)."""
         P, F = self._params, {}
         for k in list(P):
             if k.endswith(".attn1.query_proj.weight"):
@@ -186,8 +187,8 @@ class UNetModel:
                 F[f"{b}.qk"] = torch.cat([P[k], P[f"{b}.key_proj.weight"]], dim=0).contiguous()
         w = P["conv_in.weight"]
         cin = w.shape[-1]
-        if cin % 8:
-            wp = torch.zeros(*w.shape[:-1], (cin + 7) // 8 * 8, dtype=BF16, device=self.device)
+        if cin % 64:
+            wp = torch.zeros(*w.shape[:-1], (cin + 63) // 64 * 64, dtype=BF16, device=self.device)
             wp[..., :cin] = w
             F["conv_in.weight"] = wp
         else:
@@ -307,8 +308,8 @@ class UNetModel:
         mem[:, :S].copy_(encoder_x)
 
         cin = cfg.in_channels
-        if cin % 8:
-            x = ops.concat_channels(x, None, pad_to=(cin + 7) // 8 * 8)
+        if cin % 64:
+            x = ops.concat_channels(x, None, pad_to=(cin + 63) // 64 * 64)
         x = ops.conv2d(x, self._fused["conv_in.weight"], W["conv_in.bias"])
         residuals = [x]
         for blk in self.down:

@@ -98,9 +98,9 @@ class Autoencoder:
         return self.finalize()
 
     def finalize(self) -> "Autoencoder":
-        w = self._params["decoder.conv_in.weight"]        # input channels zero-padded to 8 for the small conv
+        w = self._params["decoder.conv_in.weight"]        # input channels zero-padded to 64: MFMA implicit-GEMM path
         cin = w.shape[-1]
-        wp = torch.zeros(*w.shape[:-1], (cin + 7) // 8 * 8, dtype=BF16, device=self.device)
+        wp = torch.zeros(*w.shape[:-1], (cin + 63) // 64 * 64, dtype=BF16, device=self.device)
         wp[..., :cin] = w
         self._conv_in_w = wp
         return self
@@ -148,8 +148,8 @@ class Autoencoder:
         cfg, W = self.config, self._params
         z = z.to(BF16).contiguous()
         cin = cfg.latent_channels_in
-        # z / scaling_factor -> post_quant_proj (vae.py:256-258), output zero-padded to 8 channels
-        x = ops.pixel_linear(z, W["post_quant_proj.weight"], W["post_quant_proj.bias"], (cin + 7) // 8 * 8,
+        # z / scaling_factor -> post_quant_proj (vae.py:256-258), output zero-padded to 64 channels
+        x = ops.pixel_linear(z, W["post_quant_proj.weight"], W["post_quant_proj.bias"], (cin + 63) // 64 * 64,
                              self.scaling_factor)
         x = ops.conv2d(x, self._conv_in_w, W["decoder.conv_in.bias"])
         x = self._resnet("decoder.mid_blocks.0", x)
