@@ -70,3 +70,15 @@ DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 DEVINL void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
+#include <type_traits>
+#include <utility>
+template <int B, int... Is, class F>
+DEVINL void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, B + Is>{}), ...);
+}
+template <int B, int E, class F>
+DEVINL void static_for(F&& f) {
+  static_for_impl<B>(static_cast<F&&>(f), std::make_integer_sequence<int, E - B>{});
+}

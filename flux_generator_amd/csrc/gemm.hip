@@ -64,6 +64,11 @@ const TileCfg kCfgs[] = {
     make_cfg<128, 128, 2, 4, 3, 4>(),     // 40: cfg 28 "
     make_cfg<256, 128, 4, 2, 3, 4>(),     // 41: cfg 29 "
     make_cfg<256, 256, 4, 2, 2, 4, 1>(),  // 42: cfg 36, phase-timed
+    make_cfg<256, 256, 4, 2, 2, 5>(),     // 43: cfg 36 with the fragment reads spread between the MFMAs too
+    make_cfg<256, 224, 4, 2, 2, 5>(),     // 44: cfg 37 "
+    make_cfg<256, 192, 4, 2, 2, 5>(),     // 45: cfg 38 "
+    make_cfg<256, 128, 4, 2, 3, 5>(),     // 46: cfg 41 "
+    make_cfg<128, 128, 2, 4, 3, 5>(),     // 47: cfg 40 "
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -76,11 +81,11 @@ unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 // With cold (HBM-streamed) weights the fit is within 3-6 % for the one-block-per-CU tiles.
 struct Cand { int cfg; int bpc; float t_step_us; float t_fixed_us; };
 const Cand kCands[] = {
-    {36, 1, 1.236f, 21.1f},   // 256x256, spread LDS-DMA, 2 + 3 ring
-    {37, 1, 1.221f, 17.8f},   // 256x224
-    {38, 1, 1.050f, 16.5f},   // 256x192
+    {43, 1, 1.210f, 21.1f},   // 256x256, LDS-DMA pieces and fragment reads spread between MFMAs, 2 + 3 ring
+    {44, 1, 1.150f, 17.8f},   // 256x224
+    {45, 1, 1.010f, 16.5f},   // 256x192
     {30, 1, 1.000f, 13.0f},   // 256x160
-    {41, 1, 0.790f, 11.2f},   // 256x128
+    {46, 1, 0.760f, 11.2f},   // 256x128
     {31, 1, 0.863f, 10.0f},   // 128x256
     {40, 1, 0.574f, 5.56f},   // 128x128, 8 waves
     {7, 2, 0.903f, 10.2f},    // 128x128, 4 waves, 2 blocks/CU

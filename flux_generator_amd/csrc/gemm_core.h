@@ -351,7 +351,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     if constexpr (TIMED) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_loop0)::"memory");
 #define GEMM_STAMP(i) \
     if constexpr (TIMED) { asm volatile("s_memtime %0" : "=s"(ts[i])::"memory"); }
-    if constexpr (PIPE == 4) {
+    if constexpr (PIPE >= 4) {
       // Spread LDS-DMA issue.  The CU's texture-address path takes ~16 cycles per 1-KiB piece, so the 64
       // pieces of a K-step issued back to back after the barrier (PIPE 1/3) hold every wave in the issue
       // queue for ~700 cycles with the MFMA pipes idle (tools/gemm_phase_trace.py).  Here each piece is
@@ -360,25 +360,45 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       // Issue order: prologue A0 W0 .. A(NSA-1) W(NSA-1) W(NSA) .. W(NSW-2); iteration j: W(j+NSW-1), [wait,
       // barrier], A(j+NSA).  When step kt+1 is needed, the loads younger than A(kt+1) are NSA-1 weight
       // steps and NSA-2 activation steps.
-      static_assert(NSW == NSA + 1, "PIPE 4 needs the deeper weight ring");
+      // PIPE 5 also spreads the fragment reads: the 12..16 ds_reads of the next MFMA cluster are issued one
+      // per MFMA inside the current cluster instead of in a block before it (each block of reads kept the
+      // matrix pipe waiting ~150-250 cycles, twice per K-step).
+      constexpr bool RDS = PIPE == 5;
+      static_assert(NSW == NSA + 1, "PIPE 4/5 need the deeper weight ring");
       constexpr int PEND4 = (NSA - 1) * BPW + (NSA - 2) * APW;
       constexpr int NM = MI * NJ;
-      auto mma_spread = [&](const bf16x8(&af)[MI], const bf16x8(&wf)[NJ], auto&& piece, const int np) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-            const int idx = i * NJ + j + 1;
-#pragma unroll
-            for (int q = 0; q < np; ++q)
-              if (idx == q * NM / np + NM / (2 * np)) {
-                __builtin_amdgcn_sched_barrier(0);
-                piece(q);
-                __builtin_amdgcn_sched_barrier(0);
-              }
+      // (compile-time indices throughout: a fragment that is only conditionally written costs a second live copy)
+      auto no_read = [](auto) {};
+      auto mma_spread = [&](const bf16x8(&af)[MI], const bf16x8(&wf)[NJ], auto&& piece, auto np_tag, auto&& rd,
+                            auto nrd_tag) {
+        constexpr int np = decltype(np_tag)::value, nrd = decltype(nrd_tag)::value;
+        static_for<0, NM>([&](auto I) {
+          constexpr int i = I.value / NJ, j = I.value % NJ, idx = I.value + 1;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          if constexpr (idx <= nrd) {
+            __builtin_amdgcn_sched_barrier(0);
+            rd(std::integral_constant<int, idx - 1>{});
+            __builtin_amdgcn_sched_barrier(0);
           }
+          if constexpr (np > 0) {
+            if constexpr ((idx - NM / (2 * np)) % (NM / np) == 0 && idx >= NM / (2 * np)) {
+              __builtin_amdgcn_sched_barrier(0);
+              piece((idx - NM / (2 * np)) / (NM / np));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        });
       };
+      // fragment read number r of a cluster: r < MI -> activation fragment r, else weight fragment r - MI
+      auto read_one = [&](bf16x8(&af)[MI], bf16x8(&wf)[NJ], uint32_t aa, uint32_t bb, auto r_tag) {
+        constexpr int r = decltype(r_tag)::value;
+        if constexpr (r < MI)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[r]) : "v"(aa), "n"(r * 2048) : "memory");
+        else
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[r - MI]) : "v"(bb), "n"((r - MI) * 2048) : "memory");
+      };
+      constexpr int NRD = (MI + NJ) <= NM ? (MI + NJ) : NM;
+      static_assert(!RDS || MI + NJ <= NM, "spread reads need at least as many MFMAs as fragments");
 #pragma unroll
       for (int s = 0; s < NSA; ++s)
         if (s < nkt) { stage_a(s, s); stage_w(s, s); }
@@ -396,11 +416,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
         const int nw = (cw + 1 == NSW) ? 0 : cw + 1;
         const bool more_w = kt + NSW - 1 < nkt, more_a = kt + NSA < nkt;
         GEMM_STAMP(0)
-        read_frags(a1, w1, ca, cw, 1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TIMED ? (NF > 1 ? NF - 1 : 0) : NF) : "memory");
+        if constexpr (RDS) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // a0/w0 (requested inside the previous cluster)
+        } else {
+          read_frags(a1, w1, ca, cw, 1);
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TIMED ? (NF > 1 ? NF - 1 : 0) : NF) : "memory");
+        }
         GEMM_STAMP(1)
         __builtin_amdgcn_sched_barrier(0);
-        mma_spread(a0, w0, [&](int q) { if (more_w) stage_w(kt + NSW - 1, pw, q, q + 1); }, BPW);
+        using IC0 = std::integral_constant<int, 0>;
+        if constexpr (RDS) {
+          const uint32_t aa = a_rd + ca * A_BYTES + foff[1], bb = b_rd + cw * B_BYTES + foff[1];
+          mma_spread(a0, w0, [&](int q) { if (more_w) stage_w(kt + NSW - 1, pw, q, q + 1); },
+                     std::integral_constant<int, BPW>{}, [&](auto r) { read_one(a1, w1, aa, bb, r); },
+                     std::integral_constant<int, NRD>{});
+        } else {
+          mma_spread(a0, w0, [&](int q) { if (more_w) stage_w(kt + NSW - 1, pw, q, q + 1); },
+                     std::integral_constant<int, BPW>{}, no_read, IC0{});
+        }
         __builtin_amdgcn_sched_barrier(0);
         GEMM_STAMP(2)
         if (kt + 1 < nkt) {
@@ -411,13 +444,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
           __builtin_amdgcn_s_barrier();
           GEMM_STAMP(4)
           GEMM_STAMP(5)
-          read_frags(a0, w0, na, nw, 0);
+          if constexpr (!RDS) read_frags(a0, w0, na, nw, 0);
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         GEMM_STAMP(6)
         __builtin_amdgcn_sched_barrier(0);
-        mma_spread(a1, w1, [&](int q) { if (more_a) stage_a(kt + NSA, ca, q, q + 1); }, APW);
+        if constexpr (RDS) {
+          // (past the last step this re-reads a valid slot into registers nobody uses: keeps the loop branch-free)
+          const uint32_t aa = a_rd + na * A_BYTES + foff[0], bb = b_rd + nw * B_BYTES + foff[0];
+          mma_spread(a1, w1, [&](int q) { if (more_a) stage_a(kt + NSA, ca, q, q + 1); },
+                     std::integral_constant<int, APW>{}, [&](auto r) { read_one(a0, w0, aa, bb, r); },
+                     std::integral_constant<int, NRD>{});
+        } else {
+          mma_spread(a1, w1, [&](int q) { if (more_a) stage_a(kt + NSA, ca, q, q + 1); },
+                     std::integral_constant<int, APW>{}, no_read, IC0{});
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TIMED) {
           asm volatile("s_memtime %0" : "=s"(ts[7])::"memory");
