@@ -221,7 +221,7 @@ def main() -> None:
                                    "per step: 2 x (Flux forward + Euler) + VAE decode",
                        "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
                        "denoise_step_ms": step_ms, "vae_decode_ms": decode_ms,
-                       "flux_forward_tflop": fwd_tflop, "denoise_mfma_frac": fwd_tflop / (step_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
+                       "flux_forward_tflop_per_image": fwd_tflop, "denoise_mfma_frac": B * fwd_tflop / (step_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
                        "hip_graph": not args.no_graph, "kernel_breakdown_one_forward": breakdown},
             "roofline": roofline,
         }
