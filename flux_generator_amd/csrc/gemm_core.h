@@ -199,8 +199,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     bsrc[i] = (const char*)(gW + (long long)b * w_bs + (long long)n * K) + lc * 16;
   }
 
-  // conv geometry decode (per staged row), hoisted out of the K loop.  Kept in 2 registers per piece
-  // (packed top-left tap coords, image offset in 16-byte units): the 256-wide tiles have no VGPRs to spare.
+  // conv geometry decode (per staged row), hoisted out of the K loop, 2 registers per piece (the 256-wide
+  // tiles have no VGPRs to spare):
+  //  * plain convs: cimg = signed offset, in 16-byte units, of the (possibly out-of-image) top-left tap of the
+  //    row's window; cyx = 9-bit mask of the taps that fall inside the image.  A K-step then adds one
+  //    wave-uniform (tap, channel chunk) byte offset - no per-lane coordinate arithmetic in the main loop.
+  //  * fused nearest-upsample convs: cimg = image offset (16-byte units), cyx = packed top-left tap coords;
+  //    the source pixel is ((y+dy)>>1, (x+dx)>>1), decoded per K-step.
   int cyx[APW];
   uint32_t cimg[APW];
   const char* const cX = (const char*)p.cv.X + lc * 16;
@@ -213,8 +218,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       int rem = pix - bb * hw;
       int y = rem / p.cv.Wo;
       int x = rem - y * p.cv.Wo;
-      cyx[i] = ((y * p.cv.stride - p.cv.pad) << 16) | ((x * p.cv.stride - p.cv.pad) & 0xffff);
-      cimg[i] = (uint32_t)(((long long)bb * p.cv.Hs * p.cv.Ws * p.cv.Cin) >> 3);   // Cin % 64 == 0
+      const int y0 = y * p.cv.stride - p.cv.pad, x0 = x * p.cv.stride - p.cv.pad;
+      const long long img = (long long)bb * p.cv.Hs * p.cv.Ws * p.cv.Cin;      // elements; Cin % 64 == 0
+      if (p.cv.ups) {
+        cyx[i] = (y0 << 16) | (x0 & 0xffff);
+        cimg[i] = (uint32_t)(img >> 3);
+      } else {
+        int mask = 0;
+        for (int t = 0; t < p.cv.ksize * p.cv.ksize; ++t) {
+          const int yy = y0 + (p.cv.ksize == 3 ? t / 3 : 0), xx = x0 + (p.cv.ksize == 3 ? t % 3 : 0);
+          mask |= ((yy >= 0) & (yy < p.cv.Hs) & (xx >= 0) & (xx < p.cv.Ws)) << t;
+        }
+        cyx[i] = mask;
+        cimg[i] = (uint32_t)(int)((img + ((long long)y0 * p.cv.Ws + x0) * p.cv.Cin) >> 3);
+      }
     }
   }
 
@@ -241,18 +258,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       const int c0 = cch << 6;
       const int dy = (p.cv.ksize == 3) ? tap / 3 : 0;
       const int dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
-      const int Hl = p.cv.ups ? p.cv.Hs * 2 : p.cv.Hs;   // logical input grid
-      const int Wl = p.cv.ups ? p.cv.Ws * 2 : p.cv.Ws;
+      if (!p.cv.ups) {
+        const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2;   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+          if (i < i0 || i >= i1) continue;
+          uint32_t img = cimg[i];
+          asm volatile("" : "+v"(img));      // keep the 64-bit base out of loop-invariant hoisting (VGPR budget)
+          const char* src = ((cyx[i] >> tap) & 1) ? cX + (long long)(int)img * 16 + uoff : (const char*)p.cv.zero;
+          glds16(src, sa + (wave + i * NWAVES) * 1024);
+        }
+        return;
+      }
+      const int Hl = p.cv.Hs * 2, Wl = p.cv.Ws * 2;      // logical input grid of the fused upsample
 #pragma unroll
       for (int i = 0; i < APW; ++i) {
         if (i < i0 || i >= i1) continue;
         int yy = (cyx[i] >> 16) + dy, xx = (int)(short)(cyx[i] & 0xffff) + dx;
         bool ok = (yy >= 0) & (yy < Hl) & (xx >= 0) & (xx < Wl);
-        int ys = p.cv.ups ? (yy >> 1) : yy;
-        int xs = p.cv.ups ? (xx >> 1) : xx;
         uint32_t img = cimg[i];
-        asm volatile("" : "+v"(img));        // keep the 64-bit image base out of loop-invariant hoisting (VGPR budget)
-        const char* src = ok ? cX + (long long)img * 16 + ((long long)(ys * p.cv.Ws + xs) * p.cv.Cin + c0) * 2
+        asm volatile("" : "+v"(img));
+        const char* src = ok ? cX + (long long)img * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2
                              : (const char*)p.cv.zero;
         glds16(src, sa + (wave + i * NWAVES) * 1024);
       }
