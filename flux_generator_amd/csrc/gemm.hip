@@ -55,20 +55,21 @@ const TileCfg kCfgs[] = {
     make_cfg<128, 256, 2, 4, 2, 3>(),  // 31: cfg 14, 2 + 3
     make_cfg<128, 128, 2, 2, 2, 3>(),  // 32: cfg 7, 2 + 3 (80 KiB: 2 blocks/CU)
     make_cfg<128, 128, 2, 4, 2, 3>(),  // 33: 128x128, 8 waves, 2 + 3
-    make_cfg<256, 256, 4, 2, 2, 1, 1>(),  // 34: cfg 15, phase-timed (diagnostic; see fluxhip_gemm_set_trace)
-    make_cfg<256, 256, 4, 2, 2, 3, 1>(),  // 35: cfg 24, phase-timed
+    make_cfg<256, 256, 4, 2, 2, 1>(),     // 34: (= 15; slot kept so later indices stay stable)
+    make_cfg<256, 256, 4, 2, 2, 3>(),     // 35: (= 24)
     make_cfg<256, 256, 4, 2, 2, 4>(),     // 36: cfg 24 with the LDS-DMA pieces spread between the MFMAs
     make_cfg<256, 224, 4, 2, 2, 4>(),     // 37: cfg 25 "
     make_cfg<256, 192, 4, 2, 2, 4>(),     // 38: cfg 26 "
     make_cfg<256, 256, 2, 4, 2, 4>(),     // 39: cfg 27 "
     make_cfg<128, 128, 2, 4, 3, 4>(),     // 40: cfg 28 "
     make_cfg<256, 128, 4, 2, 3, 4>(),     // 41: cfg 29 "
-    make_cfg<256, 256, 4, 2, 2, 4, 1>(),  // 42: cfg 36, phase-timed
+    make_cfg<256, 256, 4, 2, 2, 4>(),     // 42: (= 36)
     make_cfg<256, 256, 4, 2, 2, 5>(),     // 43: cfg 36 with the fragment reads spread between the MFMAs too
     make_cfg<256, 224, 4, 2, 2, 5>(),     // 44: cfg 37 "
     make_cfg<256, 192, 4, 2, 2, 5>(),     // 45: cfg 38 "
     make_cfg<256, 128, 4, 2, 3, 5>(),     // 46: cfg 41 "
     make_cfg<128, 128, 2, 4, 3, 5>(),     // 47: cfg 40 "
+    make_cfg<256, 256, 4, 2, 2, 5, 1>(),  // 48: cfg 43 with phase stamps (diagnostic: fluxhip_gemm_set_trace, tools/gemm_phase_trace.py)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

@@ -372,11 +372,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     // loads issued after A(kt+1) are W(kt+1-NSA+NSW) plus NSA-2 whole iterations:
     constexpr bool TIMED = (FLAGS & FLAG_TIMED) != 0;
     constexpr int PENDING = BPW * (NSW - NSA) + (NSA - 2) * G;   // == (NSTAGE-2)*G for a uniform ring
-    unsigned long long ts[8];
+    // phase stamps (FLAG_TIMED, PIPE 5 only): taken where the loop drains lgkmcnt anyway, so they add no wait
+    unsigned long long t_prev = 0;
     uint32_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (TIMED) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_loop0)::"memory");
-#define GEMM_STAMP(i) \
-    if constexpr (TIMED) { asm volatile("s_memtime %0" : "=s"(ts[i])::"memory"); }
+    if constexpr (TIMED) {
+      asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_loop0)::"memory");
+      t_prev = t_loop0;
+    }
+#define GEMM_STAMP(i)                                                                         \
+    if constexpr (TIMED) {                                                                    \
+      unsigned long long t_now;                                                               \
+      asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory");            \
+      tsum[i] += (uint32_t)(t_now - t_prev);                                                  \
+      t_prev = t_now;                                                                         \
+    }
     if constexpr (PIPE >= 4) {
       // Spread LDS-DMA issue.  The CU's texture-address path takes ~16 cycles per 1-KiB piece, so the 64
       // pieces of a K-step issued back to back after the barrier (PIPE 1/3) hold every wave in the issue
@@ -441,14 +450,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
         const int na = (ca + 1 == NSA) ? 0 : ca + 1;
         const int nw = (cw + 1 == NSW) ? 0 : cw + 1;
         const bool more_w = kt + NSW - 1 < nkt, more_a = kt + NSA < nkt;
-        GEMM_STAMP(0)
         if constexpr (RDS) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // a0/w0 (requested inside the previous cluster)
         } else {
           read_frags(a1, w1, ca, cw, 1);
-          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TIMED ? (NF > 1 ? NF - 1 : 0) : NF) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NF) : "memory");
         }
-        GEMM_STAMP(1)
+        if constexpr (RDS) { GEMM_STAMP(3) if (TIMED) tsum[7] += 1; }   // second cluster of the previous step + loop turn
         __builtin_amdgcn_sched_barrier(0);
         using IC0 = std::integral_constant<int, 0>;
         if constexpr (RDS) {
@@ -461,20 +469,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
                      std::integral_constant<int, BPW>{}, no_read, IC0{});
         }
         __builtin_amdgcn_sched_barrier(0);
-        GEMM_STAMP(2)
+        if constexpr (RDS) { GEMM_STAMP(0) }                                  // first cluster (MFMAs + reads + weight pieces)
         if (kt + 1 < nkt) {
           if (more_w) wait_vmcnt<PEND4>();
           else wait_vmcnt<0>();
-          GEMM_STAMP(3)
+          if constexpr (RDS) { GEMM_STAMP(1) }                                // counted LDS-DMA wait
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          GEMM_STAMP(4)
-          GEMM_STAMP(5)
+          if constexpr (RDS) { GEMM_STAMP(2) }                                // barrier
           if constexpr (!RDS) read_frags(a0, w0, na, nw, 0);
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        GEMM_STAMP(6)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (RDS) {
           // (past the last step this re-reads a valid slot into registers nobody uses: keeps the loop branch-free)
@@ -487,15 +493,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
                      std::integral_constant<int, APW>{}, no_read, IC0{});
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TIMED) {
-          asm volatile("s_memtime %0" : "=s"(ts[7])::"memory");
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-if (kt + 1 < nkt && kt > 0) {
-#pragma unroll
-          for (int i = 0; i < 7; ++i) tsum[i] += (uint32_t)(ts[i + 1] - ts[i]);
-          tsum[7] += 1;
-        }
-        }
         ca = na;
         pw = cw;
         cw = nw;
@@ -516,41 +513,25 @@ if (kt + 1 < nkt && kt > 0) {
     for (int kt = 0; kt < nkt; ++kt) {
       const int na = (ca + 1 == NSA) ? 0 : ca + 1;
       const int nw = (cw + 1 == NSW) ? 0 : cw + 1;
-      GEMM_STAMP(0)
       read_frags(a1, w1, ca, cw, 1);
-      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TIMED ? (NF > 1 ? NF - 1 : 0) : NF) : "memory");   // a0/w0 landed, a1/w1 in flight
-      GEMM_STAMP(1)
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NF) : "memory");   // a0/w0 landed, a1/w1 in flight
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, w0);
       __builtin_amdgcn_sched_barrier(0);
-      GEMM_STAMP(2)
       if (kt + 1 < nkt) {
         if (kt + NSW - 1 < nkt) wait_vmcnt<PENDING>();                // step kt+1 landed (my pieces)
         else wait_vmcnt<0>();                                          // tail: fewer steps in flight
-        GEMM_STAMP(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my reads of the current slots are done
         __builtin_amdgcn_s_barrier();                                   // ... and everybody else's
-        GEMM_STAMP(4)
         if (kt + NSA < nkt) stage_a(kt + NSA, ca);                      // refill the slots just drained
         if (kt + NSW < nkt) stage_w(kt + NSW, cw);
-        GEMM_STAMP(5)
         read_frags(a0, w0, na, nw, 0);
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      GEMM_STAMP(6)
       __builtin_amdgcn_sched_barrier(0);
       mma(a1, w1);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (TIMED) {
-        asm volatile("s_memtime %0" : "=s"(ts[7])::"memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-if (kt + 1 < nkt && kt > 0) {
-#pragma unroll
-          for (int i = 0; i < 7; ++i) tsum[i] += (uint32_t)(ts[i + 1] - ts[i]);
-          tsum[7] += 1;
-        }
-      }
       ca = na;
       cw = nw;
     }

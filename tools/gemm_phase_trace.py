@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of the pipelined GEMM main loop (phase-timed tile configs, GPU box only).
-usage: gemm_phase_trace.py <timed cfg> [M N K]"""
+usage: gemm_phase_trace.py [48] [M N K]   (48 = the phase-stamped 256x256 PIPE-5 tile)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flux_generator_amd import ops, _lib
 
 lib = _lib.load()
-cfg = int(sys.argv[1])
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 M, N, K = (int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 else (1280, 21504, 3072)
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
@@ -24,12 +24,12 @@ torch.cuda.synchronize()
 lib.fluxhip_gemm_set_trace(None)
 t = trace.view(-1, 16).cpu().double()
 t = t[t[:, 7] > 0]
-per = t[:, :7] / t[:, 7:8]
-names = ["rd a1 + wait a0", "mma(a0) issue", "vmcnt wait", "lgkm0 + barrier", "DMA issue", "rd a0 issue", "mma(a1) issue"]
+per = t[:, :4] / t[:, 7:8]
+names = ["cluster 1 (32 MFMA + next reads + W pieces)", "LDS-DMA wait", "barrier", "cluster 2 (32 MFMA + next reads + A pieces) + loop turn"]
 mean = per.mean(0)
 print(f"cfg {cfg}  M={M} N={N} K={K}: {len(t)} waves, mean cycles per K-step = {float(mean.sum()):.0f} (+ stamp overhead)")
 for n, v, lo, hi in zip(names, mean, per.min(0).values, per.max(0).values):
-    print(f"  {n:18s} {float(v):7.0f}   [{float(lo):.0f} .. {float(hi):.0f}]")
+    print(f"  {n:58s} {float(v):7.0f}   [{float(lo):.0f} .. {float(hi):.0f}]")
 tot, rt, pro, epi = (float(t[:, i].mean()) for i in (8, 9, 10, 11))
 print(f"  whole wave {tot:.0f} cycles = {rt / 100:.1f} us -> shader clock {tot / rt * 0.1:.2f} GHz; setup {pro:.0f}, "
       f"main loop {tot - pro - epi:.0f}, epilogue {epi:.0f} cycles")
