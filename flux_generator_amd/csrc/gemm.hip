@@ -70,6 +70,13 @@ const TileCfg kCfgs[] = {
     make_cfg<256, 128, 4, 2, 3, 5>(),     // 46: cfg 41 "
     make_cfg<128, 128, 2, 4, 3, 5>(),     // 47: cfg 40 "
     make_cfg<256, 256, 4, 2, 2, 5, 1>(),  // 48: cfg 43 with phase stamps (diagnostic: fluxhip_gemm_set_trace, tools/gemm_phase_trace.py)
+    make_cfg<256, 256, 4, 2, 2, 6>(),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
+    make_cfg<256, 224, 4, 2, 2, 6>(),     // 50: cfg 44 "
+    make_cfg<256, 192, 4, 2, 2, 6>(),     // 51: cfg 45 "
+    make_cfg<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
+    make_cfg<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
+    make_cfg<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
+    make_cfg<128, 256, 2, 4, 2, 6>(),     // 55: 128x256, ping-pong
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -78,17 +85,17 @@ unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
 // Tile choice: time model fitted to tools/gemm_tune.py sweeps (profiles/r01_gemm_tune_*.txt):
 //   time = ceil(tiles / (256 CUs x blocks/CU)) x (K/64 x t_step + t_fixed)
-// t_step = one K-step of the main loop, t_fixed = prologue fill + epilogue + launch tail of one tile round.
-// With cold (HBM-streamed) weights the fit is within 3-6 % for the one-block-per-CU tiles.
+// t_step = one K-step of the main loop, t_fixed = prologue fill + epilogue + launch tail of one tile round
+// (tools/fit_tiles.py).  With cold (HBM-streamed) weights the fit is within 4-8 % for the one-block-per-CU tiles.
 struct Cand { int cfg; int bpc; float t_step_us; float t_fixed_us; };
 const Cand kCands[] = {
-    {43, 1, 1.210f, 21.1f},   // 256x256, LDS-DMA pieces and fragment reads spread between MFMAs, 2 + 3 ring
-    {44, 1, 1.150f, 17.8f},   // 256x224
-    {45, 1, 1.010f, 16.5f},   // 256x192
-    {30, 1, 1.000f, 13.0f},   // 256x160
-    {46, 1, 0.760f, 11.2f},   // 256x128
-    {31, 1, 0.863f, 10.0f},   // 128x256
-    {40, 1, 0.574f, 5.56f},   // 128x128, 8 waves
+    {49, 1, 1.072f, 22.1f},   // 256x256, ping-pong schedule, 2 + 3 ring
+    {50, 1, 1.010f, 18.7f},   // 256x224  "
+    {51, 1, 0.875f, 17.0f},   // 256x192  "
+    {54, 1, 0.819f, 14.3f},   // 256x160  "
+    {46, 1, 0.748f, 12.1f},   // 256x128, spread LDS-DMA + fragment reads, 3 + 4 ring
+    {55, 1, 0.787f, 10.9f},   // 128x256, ping-pong
+    {47, 1, 0.564f, 5.71f},   // 128x128, 8 waves, spread reads
     {7, 2, 0.903f, 10.2f},    // 128x128, 4 waves, 2 blocks/CU
     {8, 2, 0.847f, 0.30f},    // 128x64
     {9, 2, 0.672f, 2.90f},    // 64x128

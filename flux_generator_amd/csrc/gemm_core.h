@@ -102,6 +102,8 @@ template <int BM, int BN, int WM, int WN, int AMODE, int NSTAGE, int PIPE, int F
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p) {
   constexpr int BK = 64;
   constexpr int NWAVES = WM * WN;
+  constexpr bool PP = PIPE == 6 && AMODE == 0;     // ping-pong schedule (dense loader only; conv falls back to PIPE 5)
+  constexpr int PIPEX = (PIPE == 6 && AMODE == 1) ? 5 : PIPE;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   // one slot deeper than the activation ring (PIPE 3): weights are the cold HBM stream (every line is a
   // compulsory miss for the XCD), activations are re-read by every N-tile and mostly hit L2, and 2 x 32 KiB
   // + 3 x 32 KiB is exactly the 160 KiB of a CU for the 256 x 256 tile.
-  constexpr int NSA = NSTAGE, NSW = (PIPE >= 3) ? NSTAGE + 1 : NSTAGE;
+  constexpr int NSA = NSTAGE, NSW = (PIPEX >= 3) ? NSTAGE + 1 : NSTAGE;
   constexpr int W_BASE = NSA * A_BYTES;
   // [i0, i1) = the subset of this wave's pieces to issue (PIPE 4 spreads them between MFMAs)
   auto stage_a = [&](int kt, int slot, int i0 = 0, int i1 = 64) {
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
   };
 
-  if constexpr (PIPE == 0) {
+  if constexpr (PIPEX == 0) {
     // simple ring: wait -> barrier -> refill the freed slot -> read fragments -> MFMA
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
@@ -386,7 +388,101 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       tsum[i] += (uint32_t)(t_now - t_prev);                                                  \
       t_prev = t_now;                                                                         \
     }
-    if constexpr (PIPE >= 4) {
+    if constexpr (PP) {
+// Ping-pong schedule (PIPE 6).  The 8 waves form two groups, one wave of each per SIMD (waves w and w+4
+      // share a SIMD).  A K-step has two phases separated by block barriers; in each phase one group issues its 64
+      // MFMAs back to back while the other does its memory work (24 fragment reads for its next MFMA phase plus
+      // its share of the LDS-DMA: group 0 stages the activation tiles, group 1 the weight tiles), then they swap:
+      //      group 0:  MFMA(kt) | B1 | read(kt+1), A(kt+2) -> slot kt%2      | B2
+      //      group 1:  read(kt), W(kt+2) -> slot (kt+2)%3, wait W(kt+1) | B1 | MFMA(kt) | B2
+      // so a SIMD always has exactly one wave feeding the matrix pipe, and that wave has nothing else to issue.
+      // (The spread loops above let both waves of a SIMD run the same mix; the phase trace showed one of them
+      //  winning the pipe, finishing early and idling at the barrier while the other ran alone at ~2/3 rate.)
+      // Hazards: a slot is refilled one barrier after its last reader drained lgkmcnt; a group waits (vmcnt) for
+      // its own pieces before the barrier that publishes them.  See DESIGN.md 3.1.
+      static_assert(NSA == 2 && NSW == 3 && NWAVES == 8, "ping-pong: 8 waves, 2 + 3 ring");
+      constexpr int LW = NWAVES / 2;
+      constexpr int PA = BM / 8 / LW, PB = (BPIECES + LW - 1) / LW, PW = PA > PB ? PA : PB;
+      static_assert(BM % (8 * LW) == 0, "activation pieces per loader wave");
+      const bool g0 = wave < LW;                                   // wave-uniform
+      const int lw = g0 ? wave : wave - LW;
+      const char* src[PW];
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        if (g0) {
+          const int row = min(lw + i * LW, BM / 8 - 1) * 8 + lr;
+          src[i] = (const char*)(gA + (long long)b * a_bs + (long long)min(m0 + row, Mg - 1) * p.lda) + lc * 16;
+        } else {
+          const int row = min(lw + i * LW, BPIECES - 1) * 8 + lr;
+          src[i] = (const char*)(gW + (long long)b * w_bs + (long long)min(n0 + row, N - 1) * K) + lc * 16;
+        }
+      }
+      auto pp_stage = [&](int kt, int slot) {     // my group's operand of K-step kt into ring slot `slot`
+        const long long koff = (long long)(kt + kbase) * (BK * 2);
+        if (g0) {
+#pragma unroll
+          for (int i = 0; i < PA; ++i) glds16(src[i] + koff, smem + slot * A_BYTES + (lw + i * LW) * 1024);
+        } else {
+#pragma unroll
+          for (int i = 0; i < PB; ++i)
+            glds16(src[i] + koff, smem + W_BASE + slot * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
+        }
+      };
+      bf16x8 a0[MI], w0[NJ], a1[MI], w1[NJ];
+      // prologue: steps 0 and 1 (group 1 issues W(2) in its first memory phase)
+      pp_stage(0, 0);
+      if (nkt > 1) pp_stage(1, 1);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (g0) {
+        read_frags(a0, w0, 0, 0, 0);
+        read_frags(a1, w1, 0, 0, 1);
+      }
+      // Two separate loops (not one loop with a group branch inside): every fragment and accumulator register is
+      // then written unconditionally in its loop, which is what keeps hipcc from holding second copies of them.
+      if (g0) {
+        int sa = 0, sw = 0;                        // ring slots of step kt
+        for (int kt = 0; kt < nkt; ++kt) {
+          const int sa1 = sa ^ 1, sw1 = sw == 2 ? 0 : sw + 1;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          mma(a0, w0);
+          mma(a1, w1);
+          __builtin_amdgcn_sched_barrier(0);
+          wait_vmcnt<0>();                         // my A(kt+1) pieces (issued one phase ago)
+          __builtin_amdgcn_s_barrier();            // B1
+          // (past the last step this re-reads a valid slot into registers nobody uses: keeps the body branch-free)
+          read_frags(a0, w0, sa1, sw1, 0);
+          read_frags(a1, w1, sa1, sw1, 1);
+          if (kt + 2 < nkt) pp_stage(kt + 2, sa);
+          __builtin_amdgcn_s_barrier();            // B2
+          sa = sa1;
+          sw = sw1;
+        }
+      } else {
+        int sa = 0, sw = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+          const int sw1 = sw == 2 ? 0 : sw + 1, sw2 = sw1 == 2 ? 0 : sw1 + 1;
+          read_frags(a0, w0, sa, sw, 0);
+          read_frags(a1, w1, sa, sw, 1);
+          if (kt + 2 < nkt) {
+            pp_stage(kt + 2, sw2);
+            wait_vmcnt<PB>();                      // W(kt+1) landed; W(kt+2) may still fly
+          } else {
+            wait_vmcnt<0>();
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slot kt are done before it is refilled
+          __builtin_amdgcn_s_barrier();            // B1
+          __builtin_amdgcn_sched_barrier(0);
+          mma(a0, w0);
+          mma(a1, w1);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();            // B2
+          sa ^= 1;
+          sw = sw1;
+        }
+      }
+    } else if constexpr (PIPEX >= 4) {
       // Spread LDS-DMA issue.  The CU's texture-address path takes ~16 cycles per 1-KiB piece, so the 64
       // pieces of a K-step issued back to back after the barrier (PIPE 1/3) hold every wave in the issue
       // queue for ~700 cycles with the MFMA pipes idle (tools/gemm_phase_trace.py).  Here each piece is
@@ -398,7 +494,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       // PIPE 5 also spreads the fragment reads: the 12..16 ds_reads of the next MFMA cluster are issued one
       // per MFMA inside the current cluster instead of in a block before it (each block of reads kept the
       // matrix pipe waiting ~150-250 cycles, twice per K-step).
-      constexpr bool RDS = PIPE == 5;
+      constexpr bool RDS = PIPEX == 5;
       static_assert(NSW == NSA + 1, "PIPE 4/5 need the deeper weight ring");
       constexpr int PEND4 = (NSA - 1) * BPW + (NSA - 2) * APW;
       constexpr int NM = MI * NJ;
