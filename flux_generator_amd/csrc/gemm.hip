@@ -107,7 +107,7 @@ const Cand kCands[] = {
 const Cand kConvCands[] = {
     {15, 1, 1.930f, 6.0f},    // 256x256
     {10, 1, 1.110f, 4.8f},    // 256x128
-    {31, 1, 1.106f, 5.4f},    // 128x256
+    {55, 1, 0.980f, 8.2f},    // 128x256, ping-pong (the address generation runs in the memory phase, off the MFMA wave)
     {7, 2, 1.155f, 4.0f},     // 128x128, 2 blocks/CU
     {8, 2, 0.847f, 0.30f},    // 128x64
     {9, 2, 0.672f, 2.90f},    // 64x128

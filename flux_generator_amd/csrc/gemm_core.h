@@ -102,8 +102,8 @@ template <int BM, int BN, int WM, int WN, int AMODE, int NSTAGE, int PIPE, int F
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p) {
   constexpr int BK = 64;
   constexpr int NWAVES = WM * WN;
-  constexpr bool PP = PIPE == 6 && AMODE == 0;     // ping-pong schedule (dense loader only; conv falls back to PIPE 5)
-  constexpr int PIPEX = (PIPE == 6 && AMODE == 1) ? 5 : PIPE;
+  constexpr bool PP = PIPE == 6;                   // ping-pong schedule
+  constexpr int PIPEX = PIPE;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
@@ -406,22 +406,71 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       static_assert(BM % (8 * LW) == 0, "activation pieces per loader wave");
       const bool g0 = wave < LW;                                   // wave-uniform
       const int lw = g0 ? wave : wave - LW;
+      // staging sources of my group's operand: dense A rows / W rows as pointers; conv A rows as the two packed
+      // geometry registers of the implicit-GEMM loader (same encoding as cyx / cimg above)
       const char* src[PW];
+      int gyx[PA];
+      uint32_t gimg[PA];
 #pragma unroll
       for (int i = 0; i < PW; ++i) {
         if (g0) {
           const int row = min(lw + i * LW, BM / 8 - 1) * 8 + lr;
-          src[i] = (const char*)(gA + (long long)b * a_bs + (long long)min(m0 + row, Mg - 1) * p.lda) + lc * 16;
+          const int grow = min(m0 + row, Mg - 1);
+          if (AMODE == 0) {
+            src[i] = (const char*)(gA + (long long)b * a_bs + (long long)grow * p.lda) + lc * 16;
+          } else if (i < PA) {
+            const int hw = p.cv.Ho * p.cv.Wo;
+            const int bb = grow / hw, rem = grow - bb * hw;
+            const int y = rem / p.cv.Wo, x = rem - y * p.cv.Wo;
+            const int y0 = y * p.cv.stride - p.cv.pad, x0 = x * p.cv.stride - p.cv.pad;
+            const long long img = (long long)bb * p.cv.Hs * p.cv.Ws * p.cv.Cin;
+            if (p.cv.ups) {
+              gyx[i] = (y0 << 16) | (x0 & 0xffff);
+              gimg[i] = (uint32_t)(img >> 3);
+            } else {
+              int mask = 0;
+              for (int t = 0; t < p.cv.ksize * p.cv.ksize; ++t) {
+                const int yy = y0 + (p.cv.ksize == 3 ? t / 3 : 0), xx = x0 + (p.cv.ksize == 3 ? t % 3 : 0);
+                mask |= ((yy >= 0) & (yy < p.cv.Hs) & (xx >= 0) & (xx < p.cv.Ws)) << t;
+              }
+              gyx[i] = mask;
+              gimg[i] = (uint32_t)(int)((img + ((long long)y0 * p.cv.Ws + x0) * p.cv.Cin) >> 3);
+            }
+          }
         } else {
           const int row = min(lw + i * LW, BPIECES - 1) * 8 + lr;
           src[i] = (const char*)(gW + (long long)b * w_bs + (long long)min(n0 + row, N - 1) * K) + lc * 16;
         }
       }
       auto pp_stage = [&](int kt, int slot) {     // my group's operand of K-step kt into ring slot `slot`
-        const long long koff = (long long)(kt + kbase) * (BK * 2);
+        long long koff = (long long)(kt + kbase) * (BK * 2);
+        int tap = 0, c0 = 0, dy = 0, dx = 0;
+        if (AMODE == 1) {                          // K order: channel chunk outer, filter tap inner
+          const int ntap = p.cv.ksize * p.cv.ksize;
+          const int cch = (kt + kbase) / ntap;
+          tap = (kt + kbase) - cch * ntap;
+          c0 = cch << 6;
+          dy = (p.cv.ksize == 3) ? tap / 3 : 0;
+          dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
+          koff = ((long long)tap * p.cv.Cin + c0) * 2;             // weight column of this (tap, chunk)
+        }
         if (g0) {
 #pragma unroll
-          for (int i = 0; i < PA; ++i) glds16(src[i] + koff, smem + slot * A_BYTES + (lw + i * LW) * 1024);
+          for (int i = 0; i < PA; ++i) {
+            const char* s_ = nullptr;
+            if (AMODE == 0) {
+              s_ = src[i] + koff;
+            } else if (!p.cv.ups) {
+              const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2;
+              s_ = ((gyx[i] >> tap) & 1) ? cX + (long long)(int)gimg[i] * 16 + uoff : (const char*)p.cv.zero;
+            } else {
+              const int yy = (gyx[i] >> 16) + dy, xx = (int)(short)(gyx[i] & 0xffff) + dx;
+              const bool ok = (yy >= 0) & (yy < p.cv.Hs * 2) & (xx >= 0) & (xx < p.cv.Ws * 2);
+              s_ = ok ? cX + (long long)gimg[i] * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2
+                      : (const char*)p.cv.zero;
+            }
+            glds16(s_, smem + slot * A_BYTES + (lw + i * LW) * 1024);
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < PB; ++i)

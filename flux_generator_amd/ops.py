@@ -216,6 +216,7 @@ def conv2d_out_image(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]
 
 
 _gn_ws = {}
+_gn_ws_retired = []
 
 
 def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6,
@@ -227,6 +228,8 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     ws = _gn_ws.get(x.device)
     need = (B * ((H * W_ + 31) // 32) * Cc + B * groups) * 2 * 4
     if ws is None or ws.numel() * 4 < need:
+        if ws is not None:
+            _gn_ws_retired.append(ws)      # a captured hipGraph may still launch kernels that point at it
         ws = torch.empty(max(need // 4, 1 << 18), dtype=torch.float32, device=x.device)
         _gn_ws[x.device] = ws
     _check(_lib.load().fluxhip_groupnorm_silu_bf16(_p(x), _p(gamma), _p(beta), _p(out), B, H * W_, Cc, groups, eps,

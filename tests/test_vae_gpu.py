@@ -97,3 +97,30 @@ def test_decoder_tiny(dev):
     # public AutoEncoder.decode (unclipped) on unpacked NHWC latents
     z = O.unpack_latents(x, (h, w))
     assert rel_l2(ae.decode(z.to(dev)), O.ae_decode(OA, W, z.float())) < 2e-2
+
+
+def test_groupnorm_workspace_growth_keeps_captured_graphs_valid(dev):
+    """The GroupNorm scratch buffer grows on demand; a hipGraph captured before the growth still points at the
+    old buffer, which therefore must stay alive (regression: SDXL UNet graph + 512x512 VAE decode)."""
+    from flux_generator_amd import ops
+    ops._gn_ws.pop(torch.device(dev), None)                # start from the small default buffer
+    x = rnd(1, 16, 16, 64, seed=1)
+    g_, b_ = rnd(64, seed=2), rnd(64, seed=3)
+    ref = ops.groupnorm_silu(x, g_, b_, 32, 1e-6, True).clone()
+    out = torch.empty_like(x)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.groupnorm_silu(x, g_, b_, 32, 1e-6, True, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.groupnorm_silu(x, g_, b_, 32, 1e-6, True, out=out)
+    big = rnd(2, 512, 512, 128, seed=4)                    # needs a much larger scratch buffer -> re-allocation
+    ops.groupnorm_silu(big, rnd(128, seed=5), rnd(128, seed=6), 32, 1e-6, True)
+    junk = [torch.full((1 << 20,), 7.0, device=dev) for _ in range(8)]   # recycle whatever was freed
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    del junk
