@@ -761,12 +761,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
     for (int i = 0; i < MI; ++i) brow[i] = rowb ? bf2f(gBias[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)]) : 0.f;
   }
-  auto biased = [&](int i, int j, int m, int n4, float (&v)[4]) {
+  // (ADDVEC is a compile-time tag so the common path carries no per-tile branch or integer division)
+  auto biased = [&](auto addvec_tag, int i, int j, int m, int n4, float (&v)[4]) {
     v[0] = acc[i][j][0] * alpha + (bf_lo(bcol[j][0]) + brow[i]);
     v[1] = acc[i][j][1] * alpha + (bf_hi(bcol[j][0]) + brow[i]);
     v[2] = acc[i][j][2] * alpha + (bf_lo(bcol[j][1]) + brow[i]);
     v[3] = acc[i][j][3] * alpha + (bf_hi(bcol[j][1]) + brow[i]);
-    if (p.addvec) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
+    if constexpr (decltype(addvec_tag)::value) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
       u32x2 aw = *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
       v[0] = rbf(v[0]) + bf_lo(aw[0]);
       v[1] = rbf(v[1]) + bf_hi(aw[0]);
@@ -818,22 +819,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   auto cswz = [](int c, int row) { return (NCH & (NCH - 1)) == 0 ? (c ^ (row & (NCH - 1))) : (c + row) % NCH; };
   if (wide) {
     // phase A: registers -> LDS
+    auto phase_a = [&](auto addvec_tag) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int row = i * 16 + r16;
-      const int m = min(m0 + wm * WTM + row, Mg - 1);
+      for (int i = 0; i < MI; ++i) {
+        const int row = i * 16 + r16;
+        const int m = min(m0 + wm * WTM + row, Mg - 1);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int n4 = min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4);
-        float v[4];
-        biased(i, j, m, n4, v);
-        u32x2 o;
-        o[0] = pack_bf16x2(v[0], v[1]);
-        o[1] = pack_bf16x2(v[2], v[3]);
-        const int ch = cswz(j * 2 + (q4 >> 1), row);
-        *(u32x2*)(my_lds + row * (NCH * 16) + ch * 16 + (q4 & 1) * 8) = o;
+        for (int j = 0; j < NJ; ++j) {
+          const int n4 = min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4);
+          float v[4];
+          biased(addvec_tag, i, j, m, n4, v);
+          u32x2 o;
+          o[0] = pack_bf16x2(v[0], v[1]);
+          o[1] = pack_bf16x2(v[2], v[3]);
+          const int ch = cswz(j * 2 + (q4 >> 1), row);
+          *(u32x2*)(my_lds + row * (NCH * 16) + ch * 16 + (q4 & 1) * 8) = o;
+        }
       }
-    }
+    };
+    if (p.addvec) phase_a(std::true_type{});
+    else phase_a(std::false_type{});
     if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_epiA)::"memory");
     // phase B: LDS -> 8 consecutive columns per lane -> global
     constexpr int NIT = (WTM * NCH + 63) / 64;
@@ -868,7 +873,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
         const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
         if (n4 >= N) continue;
         float v[4];
-        biased(i, j, m, n4, v);
+        if (p.addvec) biased(std::true_type{}, i, j, m, n4, v);
+        else biased(std::false_type{}, i, j, m, n4, v);
         if (p.out_f32) {
           float* fdst = (float*)gC + (long long)b * c_bs + (long long)m * p.ldc + n4;
           *(f32x4*)fdst = f32x4{v[0], v[1], v[2], v[3]};
