@@ -402,23 +402,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       // its own pieces before the barrier that publishes them.  See DESIGN.md 3.1.
       static_assert(NSA == 2 && NSW == 3 && NWAVES == 8, "ping-pong: 8 waves, 2 + 3 ring");
       constexpr int LW = NWAVES / 2;
-      constexpr int PA = BM / 8 / LW, PB = (BPIECES + LW - 1) / LW, PW = PA > PB ? PA : PB;
+      constexpr int PA = BM / 8 / LW, PB = (BPIECES + LW - 1) / LW;
       static_assert(BM % (8 * LW) == 0, "activation pieces per loader wave");
       const bool g0 = wave < LW;                                   // wave-uniform
       const int lw = g0 ? wave : wave - LW;
-      // staging sources of my group's operand: dense A rows / W rows as pointers; conv A rows as the two packed
-      // geometry registers of the implicit-GEMM loader (same encoding as cyx / cimg above)
-      const char* src[PW];
-      int gyx[PA];
-      uint32_t gimg[PA];
+      bf16x8 a0[MI], w0[NJ], a1[MI], w1[NJ];
+      // Two separate code paths, each with its own staging sources, prologue and loop (not one loop with a group
+      // branch inside): every fragment and accumulator register is then written unconditionally in its loop -
+      // which keeps hipcc from holding second copies of them - and a wave only carries the address registers
+      // of the operand it stages.
+      if (g0) {
+        // ---- group 0: stages the activation tile.  Dense rows as pointers; conv rows as the two packed
+        //      geometry registers of the implicit-GEMM loader (same encoding as cyx / cimg above).
+        const char* src[PA];
+        int gyx[PA];
+        uint32_t gimg[PA];
 #pragma unroll
-      for (int i = 0; i < PW; ++i) {
-        if (g0) {
-          const int row = min(lw + i * LW, BM / 8 - 1) * 8 + lr;
+        for (int i = 0; i < PA; ++i) {
+          const int row = (lw + i * LW) * 8 + lr;
           const int grow = min(m0 + row, Mg - 1);
           if (AMODE == 0) {
             src[i] = (const char*)(gA + (long long)b * a_bs + (long long)grow * p.lda) + lc * 16;
-          } else if (i < PA) {
+          } else {
             const int hw = p.cv.Ho * p.cv.Wo;
             const int bb = grow / hw, rem = grow - bb * hw;
             const int y = rem / p.cv.Wo, x = rem - y * p.cv.Wo;
@@ -437,29 +442,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
               gimg[i] = (uint32_t)(int)((img + ((long long)y0 * p.cv.Ws + x0) * p.cv.Cin) >> 3);
             }
           }
-        } else {
-          const int row = min(lw + i * LW, BPIECES - 1) * 8 + lr;
-          src[i] = (const char*)(gW + (long long)b * w_bs + (long long)min(n0 + row, N - 1) * K) + lc * 16;
         }
-      }
-      auto pp_stage = [&](int kt, int slot) {     // my group's operand of K-step kt into ring slot `slot`
-        long long koff = (long long)(kt + kbase) * (BK * 2);
-        int tap = 0, c0 = 0, dy = 0, dx = 0;
-        if (AMODE == 1) {                          // K order: channel chunk outer, filter tap inner
-          const int ntap = p.cv.ksize * p.cv.ksize;
-          const int cch = (kt + kbase) / ntap;
-          tap = (kt + kbase) - cch * ntap;
-          c0 = cch << 6;
-          dy = (p.cv.ksize == 3) ? tap / 3 : 0;
-          dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
-          koff = ((long long)tap * p.cv.Cin + c0) * 2;             // weight column of this (tap, chunk)
-        }
-        if (g0) {
+        auto stage = [&](int kt, int slot) {       // A(kt) -> activation slot `slot`
+          int tap = 0, c0 = 0, dy = 0, dx = 0;
+          if (AMODE == 1) {                        // K order: channel chunk outer, filter tap inner
+            const int ntap = p.cv.ksize * p.cv.ksize;
+            const int cch = (kt + kbase) / ntap;
+            tap = (kt + kbase) - cch * ntap;
+            c0 = cch << 6;
+            dy = (p.cv.ksize == 3) ? tap / 3 : 0;
+            dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
+          }
 #pragma unroll
           for (int i = 0; i < PA; ++i) {
             const char* s_ = nullptr;
             if (AMODE == 0) {
-              s_ = src[i] + koff;
+              s_ = src[i] + (long long)(kt + kbase) * (BK * 2);
             } else if (!p.cv.ups) {
               const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2;
               s_ = ((gyx[i] >> tap) & 1) ? cX + (long long)(int)gimg[i] * 16 + uoff : (const char*)p.cv.zero;
@@ -471,25 +469,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
             }
             glds16(s_, smem + slot * A_BYTES + (lw + i * LW) * 1024);
           }
-        } else {
-#pragma unroll
-          for (int i = 0; i < PB; ++i)
-            glds16(src[i] + koff, smem + W_BASE + slot * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
-        }
-      };
-      bf16x8 a0[MI], w0[NJ], a1[MI], w1[NJ];
-      // prologue: steps 0 and 1 (group 1 issues W(2) in its first memory phase)
-      pp_stage(0, 0);
-      if (nkt > 1) pp_stage(1, 1);
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (g0) {
+        };
+        stage(0, 0);
+        if (nkt > 1) stage(1, 1);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
         read_frags(a0, w0, 0, 0, 0);
         read_frags(a1, w1, 0, 0, 1);
-      }
-      // Two separate loops (not one loop with a group branch inside): every fragment and accumulator register is
-      // then written unconditionally in its loop, which is what keeps hipcc from holding second copies of them.
-      if (g0) {
         int sa = 0, sw = 0;                        // ring slots of step kt
         for (int kt = 0; kt < nkt; ++kt) {
           const int sa1 = sa ^ 1, sw1 = sw == 2 ? 0 : sw + 1;
@@ -503,19 +489,41 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
           // (past the last step this re-reads a valid slot into registers nobody uses: keeps the body branch-free)
           read_frags(a0, w0, sa1, sw1, 0);
           read_frags(a1, w1, sa1, sw1, 1);
-          if (kt + 2 < nkt) pp_stage(kt + 2, sa);
+          if (kt + 2 < nkt) stage(kt + 2, sa);
           __builtin_amdgcn_s_barrier();            // B2
           sa = sa1;
           sw = sw1;
         }
       } else {
+        // ---- group 1: stages the weight tile (conv: weight column = tap * Cin + channel chunk)
+        const char* src[PB];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          const int row = min(lw + i * LW, BPIECES - 1) * 8 + lr;
+          src[i] = (const char*)(gW + (long long)b * w_bs + (long long)min(n0 + row, N - 1) * K) + lc * 16;
+        }
+        auto stage = [&](int kt, int slot) {       // W(kt) -> weight slot `slot`
+          long long koff = (long long)(kt + kbase) * (BK * 2);
+          if (AMODE == 1) {
+            const int ntap = p.cv.ksize * p.cv.ksize;
+            const int cch = (kt + kbase) / ntap;
+            koff = ((long long)((kt + kbase) - cch * ntap) * p.cv.Cin + (cch << 6)) * 2;
+          }
+#pragma unroll
+          for (int i = 0; i < PB; ++i)
+            glds16(src[i] + koff, smem + W_BASE + slot * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
+        };
+        stage(0, 0);
+        if (nkt > 1) stage(1, 1);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
         int sa = 0, sw = 0;
         for (int kt = 0; kt < nkt; ++kt) {
           const int sw1 = sw == 2 ? 0 : sw + 1, sw2 = sw1 == 2 ? 0 : sw1 + 1;
           read_frags(a0, w0, sa, sw, 0);
           read_frags(a1, w1, sa, sw, 1);
           if (kt + 2 < nkt) {
-            pp_stage(kt + 2, sw2);
+            stage(kt + 2, sw2);
             wait_vmcnt<PB>();                      // W(kt+1) landed; W(kt+2) may still fly
           } else {
             wait_vmcnt<0>();
