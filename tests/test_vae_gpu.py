@@ -124,3 +124,42 @@ def test_groupnorm_workspace_growth_keeps_captured_graphs_valid(dev):
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
     del junk
+
+
+def test_full_size_decode_properties(dev):
+    """The Flux VAE decoder at its real size (64x64x16 latent -> 512x512x3, ~2.5 TFLOP of convs): properties
+    that do not need a full-size oracle run.
+      1. repeatable bit for bit; 2. hipGraph replay == eager; 3. two identical latents in a batch == the single one
+      (tile picks and split-K change with the batch, so to bf16 tolerance); 4. range: the fused clip keeps [0, 1];
+      5. translation structure: with every conv bias, GroupNorm shift and weight of the decoder's non-final layers
+         untouched, scaling the final conv_out weights and bias by 0 gives exactly clip(0 + 1, 0, 2) / 2 = 0.5."""
+    from flux_generator_amd.flux.utils import load_ae
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ae = load_ae("flux-schnell", device=dev, seed=7)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 1024, 64, generator=g).to(BF).to(dev)
+    a = ae.decode_packed(x, (64, 64))
+    b = ae.decode_packed(x, (64, 64))
+    assert a.shape == (1, 512, 512, 3) and a.dtype == torch.float32
+    assert torch.equal(a, b)
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 and float(a.std()) > 1e-3
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ae.decode_packed(x, (64, 64))
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = ae.decode_packed(x, (64, 64))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, a)
+    c = ae.decode_packed(torch.cat([x, x], dim=0), (64, 64))
+    assert torch.equal(c[0], c[1])
+    assert rel_l2(c[0], a[0].cpu()) < 1e-2
+    ae.parameters()["decoder.conv_out.weight"].zero_()
+    ae.parameters()["decoder.conv_out.bias"].zero_()
+    z = ae.decode_packed(x, (64, 64))
+    assert torch.equal(z, torch.full_like(z, 0.5))
