@@ -470,9 +470,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
             glds16(s_, smem + slot * A_BYTES + (lw + i * LW) * 1024);
           }
         };
+        // Only step 0 has to be in LDS before the first MFMA: waiting for step 1 as well made every CU of the
+        // chip sit through a second 64-KiB fetch of the cold-start burst.  Step 1 is waited for where it is needed.
         stage(0, 0);
-        if (nkt > 1) stage(1, 1);
-        wait_vmcnt<0>();
+        if (nkt > 1) {
+          stage(1, 1);
+          wait_vmcnt<PA>();
+        } else {
+          wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         read_frags(a0, w0, 0, 0, 0);
         read_frags(a1, w1, 0, 0, 1);
@@ -514,8 +520,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
             glds16(src[i] + koff, smem + W_BASE + slot * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
         };
         stage(0, 0);
-        if (nkt > 1) stage(1, 1);
-        wait_vmcnt<0>();
+        if (nkt > 1) {
+          stage(1, 1);
+          wait_vmcnt<PB>();
+        } else {
+          wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         int sa = 0, sw = 0;
         for (int kt = 0; kt < nkt; ++kt) {
