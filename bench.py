@@ -134,11 +134,19 @@ def main() -> None:
     B = args.batch
     lat = args.image_size // 8
     L, S = (lat // 2) ** 2, 256
-    # synthetic conditioning, resident in HBM before the timed region
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x_T = torch.randn(B, lat, lat, 16, generator=g, device=dev).to(torch.bfloat16)
-    txt = (torch.randn(B, S, 4096, generator=g, device=dev) * 0.1).to(torch.bfloat16)
-    vec = torch.randn(B, 768, generator=g, device=dev).to(torch.bfloat16)
+    # synthetic conditioning, resident in HBM before the timed region.  Multi-GPU: the job is ONE
+    # batch of B x world images of one prompt, sharded by image exactly like FluxPipeline.generate_latents under
+    # torchrun (flux_generator_amd/parallel.py): rank 0 holds the (synthetic) T5 / CLIP embeddings and broadcasts them
+    # over RCCL, every rank draws the full-batch prior from the job seed and keeps its rows.
+    from flux_generator_amd import parallel
+
+    def synthetic_conditioning():
+        g = torch.Generator(device=dev).manual_seed(1234)
+        return ((torch.randn(1, S, 4096, generator=g, device=dev) * 0.1).to(torch.bfloat16),
+                torch.randn(1, 768, generator=g, device=dev).to(torch.bfloat16))
+
+    x_T, txt, vec, shard = parallel.shard_generation_inputs(B * world, (lat, lat, 16), 1234, dev, synthetic_conditioning)
+    assert x_T.shape[0] == B and shard == (rank * B, rank * B + B)
     txt_ids = torch.zeros(B, S, 3, dtype=torch.int32, device=dev)
 
     def one_pass():
@@ -172,6 +180,10 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert img.shape == (B, args.image_size, args.image_size, 3) and bool(torch.isfinite(img).all())
+    # after the timed region: uint8 images of every rank gathered on rank 0 (RCCL), as the CLI does before saving
+    gathered = pipe.gather_images(img, B * world)
+    if rank == 0:
+        assert gathered.shape == (B * world, args.image_size, args.image_size, 3) and gathered.dtype == torch.uint8
 
     # ---- denoise-step latency (one Flux forward + Euler) with HIP events on the launch stream
     x, x_ids = pipe._prepare_latent_images(x_T)
@@ -222,7 +234,7 @@ def main() -> None:
             "config": {"workload": f"{args.model.replace('flux-', 'Flux-')} {args.image_size}x{args.image_size} {args.denoise_steps}-step, "
                                    f"batch {B}/GPU, random-init weights, synthetic x_T/txt/vec resident in HBM; "
                                    "per step: 2 x (Flux forward + Euler) + VAE decode",
-                       "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
+                       "global_batch": B * world, "parallelism": f"dp{world} (batch sharded by image; txt/vec broadcast from rank 0 before and uint8 gather after the timed region, no collective inside)",
                        "denoise_step_ms": step_ms, "vae_decode_ms": decode_ms,
                        "flux_forward_tflop_per_image": fwd_tflop, "denoise_mfma_frac": B * fwd_tflop / (step_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
                        "hip_graph": not args.no_graph, "kernel_breakdown_one_forward": breakdown},

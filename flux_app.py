@@ -7,6 +7,7 @@ import base64
 import io
 import socket
 import sys
+import threading
 from typing import List, Optional, Tuple, Union
 
 from fastapi import FastAPI, HTTPException
@@ -42,6 +43,8 @@ class FluxAPI:
     """One pipeline cache shared by the HTTP routes and direct callers."""
 
     def __init__(self):
+        # libfluxhip is single-stream per process (one split-K workspace, include/fluxhip.h): requests are serialised
+        self._lock = threading.Lock()
         self.pipeline = None
         self.sd_pipeline = None
         self.current_model = None
@@ -64,6 +67,10 @@ class FluxAPI:
     def generate_images(self, prompt: str, model: str = "schnell", width: int = 512, height: int = 512,
                         steps: Optional[int] = None, guidance: float = 4.0, seed: Optional[int] = None,
                         batch_size: int = 1, n_iter: int = 1, return_pil: bool = False):
+        with self._lock:
+            return self._generate_images(prompt, model, width, height, steps, guidance, seed, batch_size, n_iter, return_pil)
+
+    def _generate_images(self, prompt, model, width, height, steps, guidance, seed, batch_size, n_iter, return_pil):
         import numpy as np
         import torch
         from PIL import Image

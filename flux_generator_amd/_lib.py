@@ -67,6 +67,7 @@ SIGNATURES = {
     "fluxhip_layernorm_affine_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p]),
     "fluxhip_concat_channels_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "fluxhip_axpbypcz_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_float, c_float, c_float, c_void_p]),
+    "fluxhip_axpbypcz_dev_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p]),
     "fluxhip_pixel_linear_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     "fluxhip_sincos_embed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fluxhip_attention_masked_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
@@ -105,19 +106,48 @@ def load() -> C.CDLL:
 
 _workspace = None          # keeps the split-K workspace tensor alive for the life of the process
 WORKSPACE_BYTES = 96 << 20
+_bound_device = None       # index of the GPU this process drives (bind_device)
 
 
 def _attach_workspace(lib) -> None:
     """Give the library its split-K workspace (include/fluxhip.h: fluxhip_set_workspace): zero-filled device
-    memory owned by this process.  One process drives one GPU, so one buffer is enough; on a
-    host without a GPU (ABI tests) nothing is attached and split-K stays off."""
+    memory owned by this process, on the process's CURRENT device (bind_device makes that the model's device).
+    One process drives one GPU, so one buffer is enough; on a host without a GPU (ABI tests)
+    nothing is attached and split-K stays off."""
     global _workspace
     try:
         import torch
         if not torch.cuda.is_available():
             return
-        _workspace = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device="cuda")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if _workspace is not None and _workspace.device == dev:
+            return
+        _workspace = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
     except Exception:       # pragma: no cover - torch missing: the C ABI is still usable without split-K
         return
     if lib.fluxhip_set_workspace(_workspace.data_ptr(), WORKSPACE_BYTES) != 0:
         raise RuntimeError("fluxhip_set_workspace failed")
+
+
+def bind_device(device):
+    """Resolve the `device=` argument of a model class to the ONE GPU this process drives and make it the current
+    device.  libfluxhip launches on the current device's stream and owns one process-wide split-K workspace
+    (include/fluxhip.h: fluxhip_set_workspace), so the contract is one process per GPU (torchrun gives every rank its
+    own); asking for a second GPU in the same process raises instead of launching kernels on the wrong device."""
+    global _bound_device
+    import torch
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise RuntimeError(f"libfluxhip needs a HIP device, got '{device}': there is no CPU fallback for this path")
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    if _bound_device is None:
+        torch.cuda.set_device(idx)
+        _bound_device = idx
+    elif _bound_device != idx:
+        raise RuntimeError(f"libfluxhip is bound to cuda:{_bound_device} in this process (one process per GPU); "
+                           f"cuda:{idx} needs its own process (torchrun --nproc-per-node N)")
+    elif torch.cuda.current_device() != idx:
+        torch.cuda.set_device(idx)
+    if _lib is not None:
+        _attach_workspace(_lib)          # the library may have been loaded before the device was chosen
+    return torch.device("cuda", idx)

@@ -90,9 +90,14 @@ __global__ __launch_bounds__(256) void axpbypcz_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ y,
                                                        const bf16_t* __restrict__ z,
                                                        bf16_t* __restrict__ out, long long n, float ca,
-                                                       float cb, float cc) {
+                                                       float cb, float cc, const float* __restrict__ coef) {
   long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= n) return;
+  if (coef) {          // coefficients in device memory: one captured hipGraph serves every sampler step
+    ca = coef[0];
+    cb = coef[1];
+    cc = coef[2];
+  }
   if (i + 1 < n) {
     uint32_t xv = *(const uint32_t*)(x + i), yv = *(const uint32_t*)(y + i);
     float o0 = ca * bf_lo(xv) + cb * bf_lo(yv), o1 = ca * bf_hi(xv) + cb * bf_hi(yv);
@@ -212,7 +217,17 @@ extern "C" int fluxhip_axpbypcz_bf16(const void* x, const void* y, const void* z
   long long threads = (n + 1) / 2;
   hipLaunchKernelGGL(axpbypcz_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)z,
-                     (bf16_t*)out, (long long)n, ca, cb, cc);
+                     (bf16_t*)out, (long long)n, ca, cb, cc, (const float*)nullptr);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_axpbypcz_dev_bf16(const void* x, const void* y, const void* z, void* out,
+                                         int64_t n, const void* coef, void* stream) {
+  if (!x || !y || !out || !coef || n < 1) return FLUXHIP_EINVAL;
+  long long threads = (n + 1) / 2;
+  hipLaunchKernelGGL(axpbypcz_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)z,
+                     (bf16_t*)out, (long long)n, 0.f, 0.f, 0.f, (const float*)coef);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 

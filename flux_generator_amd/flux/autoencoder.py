@@ -86,9 +86,9 @@ class AutoEncoder:
         self.params = params
         self.scale_factor = params.scale_factor
         self.shift_factor = params.shift_factor
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
+        if torch.device(device).type != "cuda":
             raise FluxHipError("AutoEncoder needs a HIP device: there is no CPU fallback for the decode path")
+        self.device = _lib.bind_device(device)
         _lib.load()
         self._params = {k: torch.empty(*shp, dtype=BF16, device=self.device)
                         for k, shp in decoder_weight_shapes(params).items()}

@@ -51,9 +51,9 @@ class CLIPTextModel:
         if config.hidden_act != "quick_gelu":
             raise ValueError("only quick_gelu (the FLUX.1 CLIP-L text tower) is built")
         self.config = config
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
+        if torch.device(device).type != "cuda":
             raise FluxHipError("CLIPTextModel needs a HIP device")
+        self.device = _lib.bind_device(device)
         _lib.load()
         D = config.model_dims
         shp = {"token_embedding.weight": (config.vocab_size, D), "position_embedding.weight": (config.max_length, D),

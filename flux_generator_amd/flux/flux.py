@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from .. import ops
+from .. import _lib, ops, parallel
 from .sampler import FluxSampler
 from .utils import load_ae, load_clip, load_clip_tokenizer, load_flow_model, load_t5, load_t5_tokenizer
 
@@ -40,7 +40,7 @@ class FluxPipeline:
         self.dtype = torch.bfloat16
         self.name = name
         self.t5_padding = t5_padding
-        self.device = torch.device(device)
+        self.device = _lib.bind_device(device)
         self.use_graph = use_graph
 
         self.ae = load_ae(name, device=device)
@@ -137,7 +137,30 @@ class FluxPipeline:
 
     def generate_latents(self, text: str, n_images: int = 1, num_steps: int = 35, guidance: float = 4.0,
                          latent_size: Tuple[int, int] = (64, 64), seed=None):
-        """flux/flux.py:128-155."""
+        """flux/flux.py:128-155.  Under torch.distributed (one process per GPU, launched by torchrun) the batch is
+        sharded by image: rank 0 alone runs T5 / CLIP and broadcasts txt / vec over RCCL, every rank
+        draws the full x_T from the job's seed and keeps its rows, and all yields are the LOCAL images
+        (`self.shard` = their [lo, hi) range in the batch; gather with `gather_images`)."""
+        if parallel.active():
+            def cond():
+                t5_tokens, clip_tokens = self.tokenize(text)
+                txt, _, vec = self._prepare_conditioning(1 if isinstance(text, str) else n_images, t5_tokens, clip_tokens)
+                return txt, vec
+            x_T, txt, vec, self.shard = parallel.shard_generation_inputs(n_images, (*latent_size, 16), seed, self.device,
+                                                                         cond, dtype=self.dtype)
+            n_local = x_T.shape[0]
+            txt_ids = torch.zeros((n_local, txt.shape[1], 3), dtype=torch.int32, device=self.device)
+            if n_local == 0:             # more ranks than images: this rank only takes part in the collectives
+                empty = torch.empty(0, latent_size[0] * latent_size[1] // 4, 64, dtype=self.dtype, device=self.device)
+                yield (empty, torch.empty(0, empty.shape[1], 3, dtype=torch.int32, device=self.device), txt, txt_ids, vec)
+                for _ in range(num_steps):
+                    yield empty
+                return
+            x_T, x_ids = self._prepare_latent_images(x_T)
+            yield (x_T, x_ids, txt, txt_ids, vec)
+            yield from self._denoising_loop(x_T, x_ids, txt, txt_ids, vec, num_steps=num_steps, guidance=guidance)
+            return
+        self.shard = (0, n_images)
         gen = None
         if seed is not None:
             gen = torch.Generator(device=self.device).manual_seed(seed)
@@ -147,6 +170,12 @@ class FluxPipeline:
         txt, txt_ids, vec = self._prepare_conditioning(n_images, t5_tokens, clip_tokens)
         yield (x_T, x_ids, txt, txt_ids, vec)
         yield from self._denoising_loop(x_T, x_ids, txt, txt_ids, vec, num_steps=num_steps, guidance=guidance)
+
+    def gather_images(self, images: torch.Tensor, n_images: int):
+        """Decoded float images [n_local,H,W,3] of this rank -> uint8 (truncating, txt2image.py:133) -> gathered to
+        rank 0 in batch order over RCCL.  Returns uint8 [n_images,H,W,3] on rank 0, None elsewhere; with one process
+        it is just the uint8 conversion."""
+        return parallel.gather_images(parallel.to_uint8(images).contiguous(), n_images)
 
     def decode(self, x: torch.Tensor, latent_size: Tuple[int, int] = (64, 64)) -> torch.Tensor:
         """flux/flux.py:157-162: [b,L,64] -> [b,8h,8w,3] float in [0,1] (unpack, VAE decode, clip fused).
@@ -186,9 +215,10 @@ class FluxPipeline:
         images = []
         for i in tqdm(range(len(x_t)), disable=not progress, desc="generate images"):
             images.append(self.decode(x_t[i:i + 1], latent_size))
-        images = torch.cat(images, dim=0)
+        images = (torch.cat(images, dim=0) if images else
+                  torch.empty(0, latent_size[0] * 8, latent_size[1] * 8, 3, device=self.device))
         torch.cuda.synchronize(self.device)
-        return images
+        return images        # under torchrun: this rank's images (self.shard); gather_images() collects them on rank 0
 
     def generate(self, *args, **kwargs):
         """Alias of generate_images (BASELINE.json north_star wording)."""

@@ -62,10 +62,10 @@ class Flux:
         self.out_channels = params.in_channels
         self.hidden_size = params.hidden_size
         self.num_heads = params.num_heads
-        self.device = torch.device(device)
-        self._side = None            # side stream of the launch plan (modulation GEMV under the first blocks)
-        if self.device.type != "cuda":
+        if torch.device(device).type != "cuda":
             raise FluxHipError("Flux needs a HIP device: there is no CPU fallback for the denoise path")
+        self.device = _lib.bind_device(device)
+        self._side = None            # side stream of the launch plan (modulation GEMV under the first blocks)
         _lib.load()
         self._alloc_parameters()
         self._ws: Dict[Tuple[int, int, int], dict] = {}

@@ -77,9 +77,9 @@ class T5Encoder:
         if not config.feed_forward_proj.startswith("gated") or config.feed_forward_proj.removeprefix("gated-") != "gelu":
             raise ValueError("only the gated-gelu feed-forward of T5 v1.1 is built")
         self.config = config
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
+        if torch.device(device).type != "cuda":
             raise FluxHipError("T5Encoder needs a HIP device")
+        self.device = _lib.bind_device(device)
         _lib.load()
         c, inner = config, config.d_kv * config.num_heads
         shp = {"wte.weight": (c.vocab_size, c.d_model),

@@ -77,7 +77,7 @@ def load_ae(name: str, hf_download: bool = True, device="cuda", seed: int = 1) -
     spec = configs[name]
     ae = AutoEncoder(spec.ae_params, device=device)
     if spec.ae_path is not None:
-        ae.load_weights(ae.sanitize(_load_safetensors(spec.ae_path)), strict=False)
+        ae.load_weights(ae.sanitize(_load_safetensors(spec.ae_path)))   # strict: encoder.* keys are skipped explicitly
     else:
         warnings.warn(f"{name}: no AE checkpoint configured (set AE); using random-init weights")
         ae.init_random(seed)
@@ -118,7 +118,7 @@ def load_t5(name: str, device="cuda", seed: int = 3) -> T5Encoder:
         weights = {}
         for w in files:
             weights.update(_load_safetensors(os.path.join(d, "text_encoder_2", w)))
-        return t5.load_weights(t5.sanitize(weights), strict=False)
+        return t5.load_weights(t5.sanitize(weights))    # strict: decoder.* / lm_head.* keys are skipped explicitly
     warnings.warn("T5 encoder: FLUX_TEXT_DIR not set; random-init T5-XXL encoder architecture")
     return T5Encoder(T5Config(**T5_XXL), device=device).init_random(seed)
 

@@ -294,6 +294,19 @@ def axpbypcz(x: torch.Tensor, y: torch.Tensor, z: Optional[torch.Tensor], ca: fl
     return out
 
 
+def axpbypcz_dev(x: torch.Tensor, y: torch.Tensor, z: Optional[torch.Tensor], coef: torch.Tensor,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = coef[0]*x + coef[1]*y + coef[2]*z with coef a float32[3] DEVICE tensor (graph-replayable sampler step)."""
+    _bf16c(x, "x"); _bf16c(y, "y")
+    if coef.dtype != torch.float32 or coef.numel() < 3 or not coef.is_cuda:
+        raise FluxHipError("coef must be a float32[3] device tensor")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(_lib.load().fluxhip_axpbypcz_dev_bf16(_p(x), _p(y), _p(z), _p(out), x.numel(), _p(coef), _stream()),
+           "fluxhip_axpbypcz_dev_bf16")
+    return out
+
+
 def pixel_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad_to: int, in_div: float) -> torch.Tensor:
     _bf16c(x, "x"); _bf16c(w, "w")
     Cin, Cout = x.shape[-1], w.shape[0]

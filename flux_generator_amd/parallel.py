@@ -26,6 +26,12 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+def active() -> bool:
+    """True when a process group exists (torchrun launch): the sharded code path and its collectives are used even at
+    world_size 1, so a single-GPU box exercises exactly the code an 8-GPU node runs."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous, balanced split of n images: the first n % W ranks take one extra."""
     q, r = divmod(n, world_size)
@@ -37,7 +43,7 @@ def broadcast_conditioning(txt: Optional[torch.Tensor], vec: Optional[torch.Tens
                            device=None, dtype=torch.bfloat16):
     """Rank `src` passes tensors; the others pass None + `shapes` = (txt_shape, vec_shape)."""
     rank, W = world()
-    if W == 1:
+    if not active():
         return txt, vec
     if rank != src:
         txt = torch.empty(shapes[0], dtype=dtype, device=device)
@@ -60,7 +66,7 @@ def sample_prior_sharded(shape, seed: int, device, dtype=torch.bfloat16) -> torc
 def gather_images(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:
     """local uint8 [n_local,H,W,3] -> rank dst gets [n_total,H,W,3] in batch order, others None."""
     rank, W = world()
-    if W == 1:
+    if not active():
         return local
     sizes = [shard_range(n_total, r, W) for r in range(W)]
     nmax = max(hi - lo for lo, hi in sizes)
@@ -71,6 +77,53 @@ def gather_images(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[t
     if rank != dst:
         return None
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def broadcast_seed(seed: Optional[int], device, src: int = 0) -> int:
+    """One seed for the whole job: rank `src`'s value (drawn from the clock-seeded default generator when the caller
+    passed None, like the reference's unseeded mx.random) is broadcast so every rank draws the same full batch."""
+    rank, W = world()
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    if not active():
+        return int(seed)
+    t = torch.tensor([int(seed)], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
+def shard_generation_inputs(n_images: int, latent_shape, seed: Optional[int], device, make_conditioning,
+                            dtype=torch.bfloat16, src: int = 0):
+    """The multi-GPU front half of FluxPipeline.generate_latents (flux/flux.py:138-147) for W ranks:
+
+      * one seed for the job (broadcast_seed), full-batch prior on every rank, local rows kept;
+      * `make_conditioning()` -> (txt [P,S,Dt], vec [P,Dv]) runs on rank `src` ONLY (the T5 / CLIP encoders are not
+        even evaluated on the other ranks); its shapes, then its bytes, are broadcast over RCCL/xGMI;
+      * P == 1 (one prompt for the whole batch): every rank expands it to its local image count;
+        P == n_images (one prompt per image): every rank keeps rows [lo, hi).
+
+    Returns (x_T_local [n_local,*latent_shape], txt_local, vec_local, (lo, hi)).  n_local may be 0."""
+    rank, W = world()
+    seed = broadcast_seed(seed, device, src)
+    x_T = sample_prior_sharded((n_images, *latent_shape), seed, device, dtype)
+    lo, hi = shard_range(n_images, rank, W)
+    txt = vec = None
+    meta = torch.zeros(5, dtype=torch.int64, device=device)
+    if rank == src:
+        txt, vec = make_conditioning()
+        txt, vec = txt.to(device=device, dtype=dtype).contiguous(), vec.to(device=device, dtype=dtype).contiguous()
+        meta = torch.tensor([*txt.shape, *vec.shape], dtype=torch.int64, device=device)
+    if active():
+        dist.broadcast(meta, src=src)
+    m = [int(v) for v in meta.tolist()]
+    txt, vec = broadcast_conditioning(txt, vec, shapes=(tuple(m[:3]), tuple(m[3:])), src=src, device=device, dtype=dtype)
+    if txt.shape[0] == 1:
+        txt, vec = txt.expand(hi - lo, -1, -1).contiguous(), vec.expand(hi - lo, -1).contiguous()
+    elif txt.shape[0] == n_images:
+        txt, vec = txt[lo:hi].contiguous(), vec[lo:hi].contiguous()
+    else:
+        raise ValueError(f"conditioning batch {txt.shape[0]} is neither 1 nor n_images={n_images}")
+    return x_T, txt, vec, (lo, hi)
 
 
 def to_uint8(images: torch.Tensor) -> torch.Tensor:

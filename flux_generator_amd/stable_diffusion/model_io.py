@@ -147,7 +147,7 @@ def load_autoencoder(key: str = _DEFAULT_MODEL, float16: bool = False, device="c
     model = Autoencoder(_MODELS[key]["vae_config"], device=device)
     path = _weights_file(key, _MODELS[key]["vae"])
     if path:
-        model.load_weights(_load_mapped(map_vae_weights, path), strict=False)
+        model.load_weights(_load_mapped(map_vae_weights, path))   # strict: encoder.* / quant_proj keys are skipped explicitly
     else:
         warnings.warn(f"{key}: no VAE weights under SD_WEIGHTS_DIR; using random-init weights")
         model.init_random(seed)

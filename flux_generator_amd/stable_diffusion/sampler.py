@@ -61,13 +61,26 @@ class SimpleEulerSampler:
         inv = torch.rsqrt(sigma_prev.square() + 1)
         return float((sigma.square() + 1).sqrt() * inv), float((sigma_prev - sigma) * inv), 0.0
 
+    needs_noise = False
+
+    def coeffs(self, t, t_prev):
+        """(ca, cb, cc) of x' = ca x + cb eps + cc noise for the step t -> t_prev (host floats)."""
+        return self._coeffs(t, t_prev)
+
     def step(self, eps_pred: torch.Tensor, x_t: torch.Tensor, t, t_prev, noise: Optional[torch.Tensor] = None):
         """sampler.py:76-85: ((sigma^2+1)^.5 x + eps (sigma_prev - sigma)) (sigma_prev^2+1)^-.5"""
         ca, cb, _ = self._coeffs(t, t_prev)
         return ops.axpbypcz(x_t, eps_pred, None, ca, cb)
 
+    def step_dev(self, eps_pred: torch.Tensor, x_t: torch.Tensor, coef: torch.Tensor,
+                 noise: Optional[torch.Tensor] = None):
+        """`step` with the coefficients in a device buffer (one captured graph for all steps)."""
+        return ops.axpbypcz_dev(x_t, eps_pred, noise if self.needs_noise else None, coef)
+
 
 class SimpleEulerAncestralSampler(SimpleEulerSampler):
+    needs_noise = True
+
     def _coeffs(self, t, t_prev):
         sigma, sigma_prev = self.sigmas(t), self.sigmas(t_prev)
         sigma2, sigma_prev2 = sigma.square(), sigma_prev.square()
@@ -76,9 +89,15 @@ class SimpleEulerAncestralSampler(SimpleEulerSampler):
         inv = torch.rsqrt(sigma_prev2 + 1)
         return float((sigma2 + 1).sqrt() * inv), float((sigma_down - sigma) * inv), float(sigma_up * inv)
 
-    def step(self, eps_pred, x_t, t, t_prev, noise: Optional[torch.Tensor] = None):
-        """sampler.py:89-105; draws the fresh N(0,1) itself unless `noise` is given (parity tests)."""
+    def draw_noise(self, x_t: torch.Tensor, key: Optional[torch.Generator] = None) -> torch.Tensor:
+        """The fresh N(0,1) of sampler.py:100, drawn from the run's seeded generator (the reference's
+        mx.random.seed(seed) fixes this noise too, __init__.py:242-243)."""
+        return torch.randn(x_t.shape, generator=key, device=x_t.device, dtype=torch.float32).to(x_t.dtype)
+
+    def step(self, eps_pred, x_t, t, t_prev, noise: Optional[torch.Tensor] = None,
+             key: Optional[torch.Generator] = None):
+        """sampler.py:89-105; draws the fresh N(0,1) from `key` unless `noise` is given (parity tests)."""
         ca, cb, cc = self._coeffs(t, t_prev)
         if noise is None:
-            noise = torch.randn(x_t.shape, device=x_t.device, dtype=torch.float32).to(x_t.dtype)
+            noise = self.draw_noise(x_t, key)
         return ops.axpbypcz(x_t, eps_pred, noise.contiguous(), ca, cb, cc)

@@ -129,9 +129,9 @@ def small_linear_any(x, w, b, silu_in=False, out=None, accum=False):
 class UNetModel:
     def __init__(self, config: UNetConfig, device: Union[str, torch.device] = "cuda"):
         self.config = config
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
+        if torch.device(device).type != "cuda":
             raise FluxHipError("UNetModel needs a HIP device: there is no CPU fallback for the denoise path")
+        self.device = _lib.bind_device(device)
         for i, c in enumerate(config.block_out_channels):
             if c % 64 or c // config.num_attention_heads[i] != 64:
                 raise ValueError("libfluxhip UNet path needs channels % 64 == 0 and attention head_dim 64")

@@ -57,9 +57,9 @@ class Autoencoder:
         self.config = config
         self.latent_channels = config.latent_channels_in
         self.scaling_factor = config.scaling_factor
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
+        if torch.device(device).type != "cuda":
             raise FluxHipError("Autoencoder needs a HIP device: there is no CPU fallback for the decode path")
+        self.device = _lib.bind_device(device)
         _lib.load()
         self._params = {k: torch.empty(*shp, dtype=BF16, device=self.device)
                         for k, shp in vae_decoder_weight_shapes(config).items()}

@@ -200,6 +200,11 @@ int fluxhip_concat_channels_bf16(const void* a, const void* b, void* out, int64_
  * sigma coefficients (sampler.py:76-105) and classifier-free guidance (__init__.py:77-78). */
 int fluxhip_axpbypcz_bf16(const void* x, const void* y, const void* z, void* out, int64_t n, float ca,
                           float cb, float cc, void* stream);
+/* Same, with (ca, cb, cc) read from device memory (float32[3]): the coefficients of sampler step i are written
+ * into a static buffer before a captured hipGraph of the whole UNet step is replayed, so ONE graph serves every
+ * (t, t_prev) of a run instead of one capture per step. */
+int fluxhip_axpbypcz_dev_bf16(const void* x, const void* y, const void* z, void* out, int64_t n,
+                              const void* coef, void* stream);
 
 /* Per-pixel Linear for tiny channel counts: out[p, :Cout] = W (x[p] / in_div) + bias, zero padded to
  * Cpad channels.  Autoencoder.decode's z / scaling_factor + post_quant_proj (vae.py:256-258). */

@@ -184,6 +184,19 @@ def test_sdxl_pipeline_surface(dev):
         assert len(lat) == 2 and lat[-1].shape == (2, 16, 16, 4) and bool(torch.isfinite(lat[-1].float()).all())
         img = pipe.decode(lat[-1])
         assert img.shape == (2, 32, 32, 3) and float(img.min()) >= 0 and float(img.max()) <= 1
+        # same seed -> same latents on EVERY step, incl. the ancestral sampler's fresh per-step noise (the reference's
+        # mx.random.seed(seed) fixes it, __init__.py:242-243), through the graph path and through the eager path
+        kw = dict(n_images=2, num_steps=3, cfg_weight=0.0, latent_size=(16, 16))
+        a = list(pipe.generate_latents("a photo of a cat", seed=11, **kw))
+        b = list(pipe.generate_latents("a photo of a cat", seed=11, **kw))
+        c = list(pipe.generate_latents("a photo of a cat", seed=12, **kw))
+        assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(a[0], c[0])
+        nstep = [k for k in pipe._graphs if k[0] == "step"]
+        assert len(nstep) == 1, "one captured UNet-step graph must serve every (t, t_prev)"
+        pipe.use_graph = False
+        e = list(pipe.generate_latents("a photo of a cat", seed=11, **kw))
+        pipe.use_graph = True
+        assert all(torch.equal(x, y) for x, y in zip(a, e)), "graph replay differs from the eager steps"
         with pytest.raises(ValueError):
             model_io.load_unet("no/such-model")
     finally:

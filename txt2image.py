@@ -4,6 +4,7 @@
 --quantize/-q --preload-models --output --save-raw --seed --verbose/-v --adapter --fuse-adapter
 --no-t5-padding; reference txt2image.py:43-65).  Runs on the HIP device only: there is no CPU path."""
 import argparse
+import os
 import sys
 
 import numpy as np
@@ -62,7 +63,19 @@ def main(argv=None):
     if args.quantize:
         print("Note: --quantize (MLX 4/8-bit nn.quantize) has no effect here; weights stay bf16")
 
-    flux = FluxPipeline("flux-" + args.model, t5_padding=args.t5_padding)
+    # `torchrun --nproc-per-node N txt2image.py ...`: one process per GPU, the --n-images batch is sharded by image
+    # (rank 0 encodes the prompt and broadcasts txt / vec over RCCL, rank 0 saves the gathered images)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = "cuda"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+        torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device(device))
+    flux = FluxPipeline("flux-" + args.model, t5_padding=args.t5_padding, device=device)
     dev = flux.device
     if args.preload_models:
         flux.ensure_models_are_loaded()
@@ -80,15 +93,22 @@ def main(argv=None):
     mem_gen = peak_gb(dev)
 
     decoded = [flux.decode(x_t[i:i + args.decoding_batch_size], latent_size)
-               for i in range(0, args.n_images, args.decoding_batch_size)]
+               for i in range(0, len(x_t), args.decoding_batch_size)]
     torch.cuda.synchronize(dev)
     mem_dec = peak_gb(dev)
-    x = torch.cat(decoded, dim=0)
+    x = (torch.cat(decoded, dim=0) if decoded else
+         torch.empty(0, latent_size[0] * 8, latent_size[1] * 8, 3, device=dev))
+    x = flux.gather_images(x, args.n_images)        # uint8 (truncation, like the reference); all images on rank 0
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    if x is None:                                   # ranks > 0 are done
+        return
 
     if args.save_raw:
         *name, suffix = args.output.split(".")
         stem = ".".join(name)
-        arr = (x * 255).to(torch.uint8).cpu().numpy()           # truncation, like the reference
+        arr = x.cpu().numpy()
         for i in range(len(arr)):
             Image.fromarray(arr[i]).save(".".join([stem, str(i), suffix]))
     else:
@@ -96,7 +116,7 @@ def main(argv=None):
         B, H, W, C = x.shape
         rows = args.n_rows
         x = x.reshape(rows, B // rows, H, W, C).permute(0, 2, 1, 3, 4).reshape(rows * H, B // rows * W, C)
-        Image.fromarray((x * 255).to(torch.uint8).cpu().numpy()).save(args.output)
+        Image.fromarray(x.cpu().numpy()).save(args.output)
 
     if args.verbose:
         print(f"Peak memory used for the text:       {mem_text:.3f}GB")
