@@ -67,7 +67,7 @@ def cpu_baseline_sample(T: int, threads: int) -> dict:
             x = O.single_stream_block(W, "single_blocks.0", 24, x, vec, pe)
         t_single = (time.perf_counter() - t0) / NS
     per_image = 2 * (19 * t_double + 38 * t_single)
-    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": threads, "kind": "port",
+    return {"value": 1.0 / per_image, "unit": "images/sec (transformer only: VAE decode not timed)", "cores": threads, "kind": "port",
             "sample": f"oracle fp32: {ND} x DoubleStreamBlock ({t_double:.2f} s each) + {NS} x SingleStreamBlock ({t_single:.2f} s each) "
                       f"at full width, T={T}, after one warm-up block; extrapolated to 2 steps x (19+38) blocks, VAE decode excluded"}
 
@@ -198,12 +198,16 @@ def main() -> None:
     e1.record()
     torch.cuda.synchronize()
     step_ms = e0.elapsed_time(e1) / reps
-    e0.record()
-    for _ in range(reps):
-        pipe.decode(x, (lat, lat))
-    e1.record()
-    torch.cuda.synchronize()
-    decode_ms = e0.elapsed_time(e1) / reps
+    decode_ms = {}
+    for prec in ("fp32", "bf16"):        # "fp32" = the reference's VAE arithmetic (fp32-faithful bf16x3 kernels): the one `value` uses
+        pipe.decode(x, (lat, lat), precision=prec)
+        e0.record()
+        for _ in range(reps):
+            pipe.decode(x, (lat, lat), precision=prec)
+        e1.record()
+        torch.cuda.synchronize()
+        decode_ms[prec] = e0.elapsed_time(e1) / reps
+    assert pipe.ae.precision == "fp32"
 
     # ---- roofline of the dominant kernel: per-launch HIP events over one eager pass of the plan
     ws = pipe.flow._workspace(B, S, L)
@@ -235,7 +239,9 @@ def main() -> None:
                                    f"batch {B}/GPU, random-init weights, synthetic x_T/txt/vec resident in HBM; "
                                    "per step: 2 x (Flux forward + Euler) + VAE decode",
                        "global_batch": B * world, "parallelism": f"dp{world} (batch sharded by image; txt/vec broadcast from rank 0 before and uint8 gather after the timed region, no collective inside)",
-                       "denoise_step_ms": step_ms, "vae_decode_ms": decode_ms,
+                       "denoise_step_ms": step_ms, "vae_decode_ms": decode_ms["fp32"],
+                       "vae_precision": "fp32-faithful, like the reference's fp32 AE (bf16 hi/lo planes, 3 MFMA passes, fp32 accumulate / norms / softmax)",
+                       "vae_decode_ms_bf16_storage_optin": decode_ms["bf16"],
                        "flux_forward_tflop_per_image": fwd_tflop, "denoise_mfma_frac": B * fwd_tflop / (step_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
                        "hip_graph": not args.no_graph, "kernel_breakdown_one_forward": breakdown},
             "roofline": roofline,

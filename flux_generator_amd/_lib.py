@@ -38,6 +38,17 @@ class GemmDesc(C.Structure):
     ]
 
 
+class GemmX3Desc(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("res", c_void_p),
+        ("a_lo", c_int64), ("w_lo", c_int64), ("c_lo", c_int64), ("res_lo", c_int64),
+        ("a_bstride", c_int64), ("c_bstride", c_int64), ("w_bstride", c_int64),
+        ("M", C.c_int32), ("nbatch", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldc", C.c_int32),
+        ("epi", C.c_int32), ("row_bias", C.c_int32), ("out_f32", C.c_int32), ("tile_cfg", C.c_int32),
+        ("alpha", c_float), ("_pad", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/fluxhip.h declares
 SIGNATURES = {
     "fluxhip_abi_version": (c_int, []),
@@ -75,6 +86,19 @@ SIGNATURES = {
     "fluxhip_rmsnorm_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_float, c_void_p]),
     "fluxhip_embedding_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "fluxhip_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    # fp32-faithful ("bf16x3") VAE path
+    "fluxhip_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "fluxhip_join_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "fluxhip_gemm_x3": (c_int, [C.POINTER(GemmX3Desc), c_void_p]),
+    "fluxhip_conv2d_x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64]
+                          + [c_int] * 9 + [c_void_p, c_void_p]),
+    "fluxhip_groupnorm_silu_x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64] + [c_int] * 4
+                                  + [c_float, c_int, c_void_p, c_int64, c_void_p]),
+    "fluxhip_softmax_rows_x3": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_void_p]),
+    "fluxhip_conv2d_small_x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "fluxhip_unpack_latents_x3": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 5 + [c_float, c_float, c_void_p]),
+    "fluxhip_pixel_linear_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                        c_float, c_void_p]),
 }
 
 _lib = None
@@ -95,7 +119,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fluxhip_abi_version() != 1:
+    if lib.fluxhip_abi_version() != 2:
         raise RuntimeError("libfluxhip ABI version mismatch")
     if lib.fluxhip_arch() != b"gfx950":
         raise RuntimeError("libfluxhip was not built for gfx950")

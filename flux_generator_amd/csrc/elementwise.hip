@@ -283,6 +283,194 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(
   }
 }
 
+
+// ---- fp32-faithful ("bf16x3") VAE path: split tensors (include/fluxhip.h) -------------------------
+DEVINL void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - bf_lo(hi), b - bf_hi(hi));
+}
+
+__global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi,
+                                                        bf16_t* __restrict__ lo, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  const bf16_t h = f2bf(v);
+  hi[i] = h;
+  lo[i] = f2bf(v - bf2f(h));
+}
+
+__global__ __launch_bounds__(256) void join_f32_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
+                                                       float* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = bf2f(hi[i]) + bf2f(lo[i]);
+}
+
+// unpack (flux/flux.py:159-160) + z / scale + shift (flux/autoencoder.py:353) in float32 -> split, channels
+// zero-padded to Cpad (one 64-channel K-step of the implicit-GEMM loader)
+__global__ __launch_bounds__(256) void unpack_x3_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                        long long out_lo, int B, int h, int w, int C, int Cpad,
+                                                        float scale, float shift) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * h * w * Cpad;
+  if (i >= total) return;
+  const int c = (int)(i % Cpad);
+  const long long pix = i / Cpad;
+  float v = 0.f;
+  if (c < C) {
+    const int xx = (int)(pix % w);
+    const int yy = (int)((pix / w) % h);
+    const int b = (int)(pix / ((long long)w * h));
+    const long long tok = ((long long)b * (h / 2) + (yy >> 1)) * (w / 2) + (xx >> 1);
+    v = bf2f(x[tok * (C * 4) + c * 4 + (yy & 1) * 2 + (xx & 1)]) / scale + shift;
+  }
+  const bf16_t hh = f2bf(v);
+  out[i] = hh;
+  out[i + out_lo] = f2bf(v - bf2f(hh));
+}
+
+__global__ __launch_bounds__(256) void pixel_linear_x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                              long long out_lo, long long npix, int Cin, int Cout,
+                                                              int Cpad, float in_div) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix * Cpad) return;
+  const long long p = i / Cpad;
+  const int co = (int)(i - p * Cpad);
+  float acc = 0.f;
+  if (co < Cout) {
+    acc = bias ? bias[co] : 0.f;
+    for (int c = 0; c < Cin; ++c) acc += (bf2f(x[p * Cin + c]) / in_div) * w[co * Cin + c];
+  }
+  const bf16_t hh = f2bf(acc);
+  out[i] = hh;
+  out[i + out_lo] = f2bf(acc - bf2f(hh));
+}
+
+// softmax_rows_kernel with a split (hi / lo) probability matrix and full-precision exp2
+__global__ __launch_bounds__(256) void softmax_rows_x3_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+                                                              long long p_lo, int cols, int ld, float scale_log2) {
+  __shared__ float red[8];
+  const long long row = blockIdx.x;
+  const float* sr = s + row * ld;
+  bf16_t* pr = p + row * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nch = cols >> 2;
+  float mx = -1e30f;
+  for (int c = tid; c < nch; c += 256) {
+    f32x4 w = *((const f32x4*)sr + c);
+    mx = fmaxf(mx, fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3])));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float mneg = -mx * scale_log2;
+  float sum = 0.f;
+  for (int c = tid; c < nch; c += 256) {
+    f32x4 w = *((const f32x4*)sr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum += exp2f(fmaf(w[e], scale_log2, mneg));
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wv] = sum;
+  __syncthreads();
+  const float inv = 1.f / ((red[4] + red[5]) + (red[6] + red[7]));
+  for (int c = tid; c < nch; c += 256) {
+    f32x4 w = *((const f32x4*)sr + c);
+    float e0 = exp2f(fmaf(w[0], scale_log2, mneg)) * inv, e1 = exp2f(fmaf(w[1], scale_log2, mneg)) * inv;
+    float e2 = exp2f(fmaf(w[2], scale_log2, mneg)) * inv, e3 = exp2f(fmaf(w[3], scale_log2, mneg)) * inv;
+    uint32_t h0, l0, h1, l1;
+    split2(e0, e1, h0, l0);
+    split2(e2, e3, h1, l1);
+    const u32x2 oh = {h0, h1}, ol = {l0, l1};
+    *((u32x2*)pr + c) = oh;
+    *((u32x2*)(pr + p_lo) + c) = ol;
+  }
+}
+
+// conv3x3_fewout_kernel for a split input and float32 weights: one output channel per lane group (blockIdx.y),
+// LPP = Cin/8 lanes per pixel, float32 FMAs on hi + lo.  The three output channels of a pixel run re-read the
+// same window from L1 / L2.
+template <int LPP>
+__global__ __launch_bounds__(256) void conv3x3_fewout_x3_kernel(const bf16_t* __restrict__ x, long long x_lo,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ out, int B, int H, int W,
+                                                                int Cout, int clip01) {
+  constexpr int Cin = LPP * 8, RUN = 16;
+  const int tid = threadIdx.x;
+  const int c = tid % LPP;
+  const int co = blockIdx.y;
+  const int runs_per_row = (W + RUN - 1) / RUN;
+  const long long run = (long long)blockIdx.x * (256 / LPP) + tid / LPP;
+  const long long nruns = (long long)B * H * runs_per_row;
+  const long long rr = run < nruns ? run : nruns - 1;
+  const int x0 = (int)(rr % runs_per_row) * RUN;
+  const int yy = (int)((rr / runs_per_row) % H);
+  const int b = (int)(rr / ((long long)runs_per_row * H));
+  float wv[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float* wp = w + ((long long)co * 9 + t) * Cin + c * 8;
+    const f32x4 a = *(const f32x4*)wp, d = *(const f32x4*)(wp + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      wv[t][e] = a[e];
+      wv[t][4 + e] = d[e];
+    }
+  }
+  const float bv = bias ? bias[co] : 0.f;
+  auto load_col = [&](int xq, float (&col)[3][8]) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int y = yy + ky - 1;
+      const bool ok = (y >= 0) & (y < H) & (xq >= 0) & (xq < W);
+      u32x4 h = {0, 0, 0, 0}, l = {0, 0, 0, 0};
+      if (ok) {
+        const bf16_t* p = x + (((long long)b * H + y) * W + xq) * Cin + c * 8;
+        h = *(const u32x4*)p;
+        l = *(const u32x4*)(p + x_lo);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        col[ky][2 * e] = bf_lo(h[e]) + bf_lo(l[e]);
+        col[ky][2 * e + 1] = bf_hi(h[e]) + bf_hi(l[e]);
+      }
+    }
+  };
+  float win[3][3][8];                    // win[kx][ky][channel]
+  load_col(x0 - 1, win[0]);
+  load_col(x0, win[1]);
+#pragma unroll 1
+  for (int i = 0; i < RUN; ++i) {
+    const int xx = x0 + i;
+    if (xx >= W) break;
+    load_col(xx + 1, win[2]);
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(win[kx][ky][e], wv[ky * 3 + kx][e], acc);
+#pragma unroll
+    for (int s_ = LPP >> 1; s_ > 0; s_ >>= 1) acc += __shfl_xor(acc, s_, 64);
+    if (c == 0 && run < nruns) {
+      float v = acc + bv;
+      if (clip01) v = fminf(fmaxf(v + 1.f, 0.f), 2.f) * 0.5f;
+      out[(((long long)b * H + yy) * W + xx) * Cout + co] = v;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        win[0][ky][e] = win[1][ky][e];
+        win[1][ky][e] = win[2][ky][e];
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int fluxhip_euler_step_bf16(const void* x, const void* pred, void* out, int64_t n,
@@ -373,5 +561,67 @@ extern "C" int fluxhip_rope_table_bf16(const void* ids, void* out, int64_t ntok,
   hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const int*)ids, (bf16_t*)out, (long long)ntok, n_axes,
                      a0, a1, a2, theta);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+// ---- fp32-faithful VAE path entry points ---------------------------------------------------------
+extern "C" int fluxhip_split_f32(const void* x, void* hi, void* lo, int64_t n, void* stream) {
+  if (!x || !hi || !lo || n < 1) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)x, (bf16_t*)hi, (bf16_t*)lo, (long long)n);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_join_f32(const void* hi, const void* lo, void* out, int64_t n, void* stream) {
+  if (!hi || !lo || !out || n < 1) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL(join_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)hi, (const bf16_t*)lo, (float*)out, (long long)n);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_unpack_latents_x3(const void* x, void* out, int64_t out_lo, int B, int h, int w, int C,
+                                         int Cpad, float scale, float shift, void* stream) {
+  if (!x || !out || B < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || C < 1 || Cpad < C || scale == 0.f)
+    return FLUXHIP_EINVAL;
+  const long long total = (long long)B * h * w * Cpad;
+  hipLaunchKernelGGL(unpack_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)out, (long long)out_lo, B, h, w, C, Cpad, scale, shift);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_pixel_linear_x3(const void* x, const void* w, const void* bias, void* out, int64_t out_lo,
+                                       int64_t npix, int Cin, int Cout, int Cpad, float in_div, void* stream) {
+  if (!x || !w || !out || npix < 1 || Cin < 1 || Cin > 64 || Cout < 1 || Cpad < Cout) return FLUXHIP_EINVAL;
+  const long long total = npix * Cpad;
+  hipLaunchKernelGGL(pixel_linear_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const float*)w, (const float*)bias, (bf16_t*)out, (long long)out_lo,
+                     (long long)npix, Cin, Cout, Cpad, in_div == 0.f ? 1.f : in_div);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_softmax_rows_x3(const void* s, void* p, int64_t p_lo, int64_t rows, int cols, int ld,
+                                       float scale, void* stream) {
+  if (!s || !p || rows < 1 || cols < 4 || cols % 4 || ld % 4 || ld < cols || p_lo % 4) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_x3_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)s, (bf16_t*)p, (long long)p_lo, cols, ld, scale * 1.4426950408889634f);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_conv2d_small_x3(const void* x, int64_t x_lo, const void* w, const void* bias, void* out,
+                                       int B, int H, int W, int Cin, int Cout, int clip01, void* stream) {
+  if (!x || !w || !out || B < 1 || H < 1 || W < 1 || Cout < 1 || Cout > 4 || x_lo % 8) return FLUXHIP_EINVAL;
+  if (Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512) return FLUXHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const long long npix = (long long)B * H * ((W + 15) / 16);   // runs of 16 pixels
+#define FEWOUT3(LPP)                                                                                   \
+  hipLaunchKernelGGL((conv3x3_fewout_x3_kernel<LPP>),                                                   \
+                     dim3((unsigned)((npix + (256 / LPP) - 1) / (256 / LPP)), Cout), dim3(256), 0, s,   \
+                     (const bf16_t*)x, (long long)x_lo, (const float*)w, (const float*)bias, (float*)out, B, H, \
+                     W, Cout, clip01)
+  if (Cin == 64) FEWOUT3(8);
+  else if (Cin == 128) FEWOUT3(16);
+  else if (Cin == 256) FEWOUT3(32);
+  else FEWOUT3(64);
+#undef FEWOUT3
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }

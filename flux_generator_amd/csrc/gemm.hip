@@ -10,33 +10,43 @@ struct TileCfg {
   int bm, bn, threads, lds;
   void (*dense)(const GemmParams);
   void (*conv)(const GemmParams);
+  void (*dense_x3)(const GemmParams);   // FLAG_SPLIT (bf16x3, fp32-faithful) instantiations; null for most tiles
+  void (*conv_x3)(const GemmParams);
 };
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE, int FLAGS = 0>
 constexpr TileCfg make_cfg() {
   return TileCfg{BM, BN, WM * WN * 64, (NSTAGE * BM + (PIPE >= 3 ? NSTAGE + 1 : NSTAGE) * BN) * 64 * 2,
                  gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAGS>,
-                 gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE, FLAGS>};
+                 gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE, FLAGS>, nullptr, nullptr};
+}
+// the same tile with the fp32-faithful (FLAG_SPLIT) kernels as well: only the tiles the VAE decoders use
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
+constexpr TileCfg make_cfg_x3() {
+  TileCfg c = make_cfg<BM, BN, WM, WN, NSTAGE, PIPE>();
+  c.dense_x3 = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_SPLIT>;
+  c.conv_x3 = gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE, FLAG_SPLIT>;
+  return c;
 }
 
 // index 0 is unused ("auto")
 const TileCfg kCfgs[] = {
-    TileCfg{0, 0, 0, 0, nullptr, nullptr},
+    TileCfg{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr},
     make_cfg<128, 128, 2, 2, 2, 0>(),  // 1: 64 KiB LDS, 2 blocks/CU
     make_cfg<128, 64, 2, 2, 2, 0>(),   // 2: more blocks for N=3072 outputs at small M
     make_cfg<64, 128, 2, 2, 2, 0>(),   // 3
-    make_cfg<64, 64, 2, 2, 2, 0>(),    // 4: tiny problems (N=64 final layer)
+    make_cfg_x3<64, 64, 2, 2, 2, 0>(),    // 4: tiny problems (N=64 final layer)
     make_cfg<256, 128, 4, 2, 2, 0>(),  // 5: 8 waves, 96 KiB
     make_cfg<256, 256, 2, 4, 2, 0>(),  // 6: 8 waves x (128x64), 128 KiB
-    make_cfg<128, 128, 2, 2, 2, 1>(),  // 7: fragment-pipelined variants of 1,2,3,5,6
-    make_cfg<128, 64, 2, 2, 2, 1>(),   // 8
-    make_cfg<64, 128, 2, 2, 2, 1>(),   // 9
-    make_cfg<256, 128, 4, 2, 2, 1>(),  // 10
+    make_cfg_x3<128, 128, 2, 2, 2, 1>(),  // 7: fragment-pipelined variants of 1,2,3,5,6
+    make_cfg_x3<128, 64, 2, 2, 2, 1>(),   // 8
+    make_cfg_x3<64, 128, 2, 2, 2, 1>(),   // 9
+    make_cfg_x3<256, 128, 4, 2, 2, 1>(),  // 10
     make_cfg<256, 256, 2, 4, 2, 1>(),  // 11
     make_cfg<256, 128, 4, 2, 3, 1>(),  // 12: 3-deep ring, 144 KiB
     make_cfg<128, 128, 2, 2, 3, 1>(),  // 13
     make_cfg<128, 256, 2, 4, 2, 1>(),  // 14
-    make_cfg<256, 256, 4, 2, 2, 1>(),  // 15: 8 waves x (64x128)
+    make_cfg_x3<256, 256, 4, 2, 2, 1>(),  // 15: 8 waves x (64x128)
     make_cfg<128, 128, 2, 4, 3, 1>(),  // 16: 8 waves x (64x32), 3-deep ring
     make_cfg<128, 128, 2, 2, 4, 1>(),  // 17: 4-deep ring, 128 KiB
     make_cfg<256, 224, 4, 2, 2, 1>(),  // 18: 21504 = 96 x 224 -> 480 tiles at M = 1280
@@ -68,19 +78,19 @@ const TileCfg kCfgs[] = {
     make_cfg<256, 224, 4, 2, 2, 5>(),     // 44: cfg 37 "
     make_cfg<256, 192, 4, 2, 2, 5>(),     // 45: cfg 38 "
     make_cfg<256, 128, 4, 2, 3, 5>(),     // 46: cfg 41 "
-    make_cfg<128, 128, 2, 4, 3, 5>(),     // 47: cfg 40 "
+    make_cfg_x3<128, 128, 2, 4, 3, 5>(),     // 47: cfg 40 "
     make_cfg<256, 256, 4, 2, 2, 5, 1>(),  // 48: cfg 43 with phase stamps (diagnostic: fluxhip_gemm_set_trace, tools/gemm_phase_trace.py)
-    make_cfg<256, 256, 4, 2, 2, 6>(),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
+    make_cfg_x3<256, 256, 4, 2, 2, 6>(),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
     make_cfg<256, 224, 4, 2, 2, 6>(),     // 50: cfg 44 "
     make_cfg<256, 192, 4, 2, 2, 6>(),     // 51: cfg 45 "
     make_cfg<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
     make_cfg<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
     make_cfg<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
-    make_cfg<128, 256, 2, 4, 2, 6>(),     // 55: 128x256, ping-pong
+    make_cfg_x3<128, 256, 2, 4, 2, 6>(),     // 55: 128x256, ping-pong
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-bool g_attr_set[kNumCfgs][2] = {};
+bool g_attr_set[kNumCfgs][4] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
 // Tile choice: time model fitted to tools/gemm_tune.py sweeps (profiles/r01_gemm_tune_*.txt):
@@ -112,6 +122,16 @@ const Cand kConvCands[] = {
     {8, 2, 0.847f, 0.30f},    // 128x64
     {9, 2, 0.672f, 2.90f},    // 64x128
     {4, 2, 0.483f, 1.15f},    // 64x64
+};
+
+// fp32-faithful (FLAG_SPLIT) kernels exist for these tiles only; same time model with 3 x the K-steps.
+const Cand kX3Cands[] = {
+    {49, 1, 1.072f, 22.1f}, {55, 1, 0.787f, 10.9f}, {47, 1, 0.564f, 5.71f}, {7, 2, 0.903f, 10.2f},
+    {8, 2, 0.847f, 0.30f},  {9, 2, 0.672f, 2.90f},  {4, 2, 0.483f, 1.15f},
+};
+const Cand kX3ConvCands[] = {
+    {15, 1, 1.930f, 6.0f}, {10, 1, 1.110f, 4.8f}, {55, 1, 0.980f, 8.2f}, {7, 2, 1.155f, 4.0f},
+    {8, 2, 0.847f, 0.30f}, {9, 2, 0.672f, 2.90f}, {4, 2, 0.483f, 1.15f},
 };
 
 // Split-K workspace (fluxhip_set_workspace): [kSkMaxTiles] int32 hand-off counters, then fp32 partial tiles.
@@ -146,12 +166,15 @@ int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbat
   return best_cfg;
 }
 
-int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool conv = false) {
+int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool conv = false, bool x3 = false) {
+  if (x3)   // three passes over K
+    return conv ? pick_from(kX3ConvCands, group_m, ngroups, nbatch, N, 3 * K)
+                : pick_from(kX3Cands, group_m, ngroups, nbatch, N, 3 * K);
   return conv ? pick_from(kConvCands, group_m, ngroups, nbatch, N, K)
               : pick_from(kCands, group_m, ngroups, nbatch, N, K);
 }
 
-int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s) {
+int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false) {
   const int cfg_idx = cfg_code & 0xff;
   int splits = cfg_code >> 8;
   if (splits < 1) splits = 1;
@@ -165,17 +188,19 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s) {
   if (p.ngroups == 1) p.g[1] = p.g[0];
   p.tiles_m_total = tm_total;
   p.tiles_n = (p.N + c.bn - 1) / c.bn;
-  auto fn = conv ? c.conv : c.dense;
-  if (!g_attr_set[cfg_idx][conv]) {
+  auto fn = x3 ? (conv ? c.conv_x3 : c.dense_x3) : (conv ? c.conv : c.dense);
+  if (!fn) return FLUXHIP_EINVAL;                   // this tile has no fp32-faithful instantiation
+  const int slot = (int)conv + 2 * (int)x3;
+  if (!g_attr_set[cfg_idx][slot]) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) !=
         hipSuccess)
       return FLUXHIP_ELAUNCH;
-    g_attr_set[cfg_idx][conv] = true;
+    g_attr_set[cfg_idx][slot] = true;
   }
   p.trace = g_trace;
   // LDS-transposed epilogue needs every output-side operand addressable in 16-byte units
   auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-  bool wide = !p.out_f32 && p.N % 8 == 0 && p.ldc % 8 == 0;
+  bool wide = !x3 && !p.out_f32 && p.N % 8 == 0 && p.ldc % 8 == 0;
   for (int g = 0; g < p.ngroups && wide; ++g) {
     const GemmGroup& t = p.g[g];
     wide = a16(t.C) && t.c_bstride % 8 == 0 && a16(t.res) && a16(t.gate) && t.gate_bstride % 8 == 0;
@@ -186,7 +211,7 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s) {
   p.splits = splits;
   if (splits > 1) {
     const long long tiles = (long long)tm_total * p.tiles_n;
-    if (splits > p.K / 64 || tiles > kSkMaxTiles ||
+    if (splits > (x3 ? 3 : 1) * (p.K / 64) || tiles > kSkMaxTiles ||
         (long long)kSkMaxTiles * 4 + tiles * c.bm * c.bn * 4LL > g_ws_bytes)
       return FLUXHIP_EINVAL;                        // no (or too small a) split-K workspace
     p.sk_flag = (int*)g_ws;
@@ -244,6 +269,41 @@ extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
   const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
   int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K);
   return launch(p, cfg, false, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_gemm_x3(const fluxhip_gemm_x3_desc* d, void* stream) {
+  if (!d || d->nbatch < 1 || !d->A || !d->W || !d->C || d->M <= 0) return FLUXHIP_EINVAL;
+  if (d->K <= 0 || d->K % 64 || d->N <= 0 || d->N % 4 || d->lda % 8 || d->ldc % 4) return FLUXHIP_EINVAL;
+  if (d->epi != FLUXHIP_EPI_BIAS && d->epi != FLUXHIP_EPI_GATE_RES) return FLUXHIP_EINVAL;
+  if (d->epi == FLUXHIP_EPI_GATE_RES && (!d->res || d->out_f32)) return FLUXHIP_EINVAL;
+  if ((d->a_lo | d->w_lo) % 8 || (d->c_lo | d->res_lo) % 4) return FLUXHIP_EINVAL;   // 16-byte staging / 8-byte stores
+  GemmParams p{};
+  GemmGroup& t = p.g[0];
+  t.A = (const bf16_t*)d->A;
+  t.W = (const bf16_t*)d->W;
+  t.bias = (const bf16_t*)d->bias;                  // float32 in this mode (the kernel casts back)
+  t.C = (bf16_t*)d->C;
+  t.res = (const bf16_t*)d->res;
+  t.a_bstride = d->a_bstride;
+  t.c_bstride = d->c_bstride;
+  t.w_bstride = d->w_bstride;
+  t.M = d->M;
+  p.ngroups = 1;
+  p.nbatch = d->nbatch;
+  p.N = d->N;
+  p.K = d->K;
+  p.lda = d->lda;
+  p.ldc = d->ldc;
+  p.epi = d->epi;
+  p.row_bias = d->row_bias;
+  p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+  p.out_f32 = d->out_f32;
+  p.a_lo = d->a_lo;
+  p.w_lo = d->w_lo;
+  p.c_lo = d->c_lo;
+  p.res_lo = d->res_lo;
+  int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(&t.M, 1, d->nbatch, d->N, d->K, false, true);
+  return launch(p, cfg, false, (hipStream_t)stream, true);
 }
 
 extern "C" int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d) {
@@ -314,4 +374,44 @@ extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bia
   static const int forced = [] { const char* e = getenv("FLUXHIP_CONV_CFG"); return e ? atoi(e) : 0; }();   // tuning knob
   int cfg = forced > 0 ? forced : pick_cfg(&t.M, 1, 1, Cout, p.K, true);
   return launch(p, cfg, true, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int64_t w_lo, const void* bias,
+                                 const void* res, int64_t res_lo, void* out, int64_t out_lo, int B, int Hs,
+                                 int Ws, int Cin, int Cout, int ksize, int stride, int pad, int ups,
+                                 const void* zero16, void* stream) {
+  if (!x || !w || !out || !zero16) return FLUXHIP_EINVAL;
+  if (Cin % 64 || Cout % 4 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
+    return FLUXHIP_EINVAL;
+  if ((x_lo | w_lo) % 8 || (out_lo | res_lo) % 4) return FLUXHIP_EINVAL;
+  const int Hl = ups ? Hs * 2 : Hs, Wl = ups ? Ws * 2 : Ws;
+  const int Ho = (Hl + 2 * pad - ksize) / stride + 1;
+  const int Wo = (Wl + 2 * pad - ksize) / stride + 1;
+  GemmParams p{};
+  p.cv.X = (const bf16_t*)x;
+  p.cv.zero = (const bf16_t*)zero16;
+  p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Ho; p.cv.Wo = Wo;
+  p.cv.Cin = Cin; p.cv.ksize = ksize; p.cv.stride = stride; p.cv.pad = pad; p.cv.ups = ups;
+  GemmGroup& t = p.g[0];
+  t.A = (const bf16_t*)x;
+  t.W = (const bf16_t*)w;
+  t.bias = (const bf16_t*)bias;                     // float32 [Cout]
+  t.C = (bf16_t*)out;
+  t.res = (const bf16_t*)res;
+  t.M = B * Ho * Wo;
+  p.ngroups = 1;
+  p.nbatch = 1;
+  p.N = Cout;
+  p.K = ksize * ksize * Cin;
+  p.lda = Cin;
+  p.ldc = Cout;
+  p.epi = res ? EPI_GATE_RES : EPI_BIAS;
+  p.alpha = 1.f;
+  p.a_lo = x_lo;
+  p.w_lo = w_lo;
+  p.c_lo = out_lo;
+  p.res_lo = res_lo;
+  static const int forced = [] { const char* e = getenv("FLUXHIP_CONV_X3_CFG"); return e ? atoi(e) : 0; }();   // tuning knob
+  int cfg = forced > 0 ? forced : pick_cfg(&t.M, 1, 1, Cout, p.K, true, true);
+  return launch(p, cfg, true, (hipStream_t)stream, true);
 }

@@ -85,10 +85,22 @@ struct GemmParams {
   int* sk_flag;          // [tiles] hand-off counters, zero between launches
   int wide_epi;          // outputs / residual / gate are 16-byte addressable: LDS-transposed epilogue
   unsigned long long* trace;  // FLAG_TIMED kernels only: [nblk][nwaves][8] summed segment cycles
+  // FLAG_SPLIT kernels only ("bf16x3": fp32-faithful products on the bf16 matrix cores).  Every operand is a pair
+  // of bf16 planes (hi = bf16(x), lo = bf16(x - hi)); the lo plane sits `*_lo` ELEMENTS after the hi pointer.
+  // bias is float32.  See the FLAG_SPLIT note at the kernel.
+  long long a_lo, w_lo, c_lo, res_lo;
 };
 
 enum GemmFlags : int {
   FLAG_TIMED = 1,     // s_memtime stamps around the phases of the pipelined loop (diagnostic tile configs only)
+  // fp32-faithful mode for the VAE decoders, which the reference runs in fp32 (flux/utils.py:137-143 keeps the
+  // checkpoint dtype; stable_diffusion/__init__.py:25 load_autoencoder(model, False)).  An fp32 value x is held as
+  // two bf16 planes x = hi + lo (+ O(2^-17 |x|)); a product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi
+  // (the dropped a_lo*w_lo is O(2^-16) relative), all three on v_mfma_f32_16x16x32_bf16 into the SAME fp32
+  // accumulators: 3x the MFMA work at 16x the fp32-MFMA rate.  The main loop is unchanged: its K-step index g
+  // runs over 3 * K/64 steps, g -> (operand step g / 3, pass g % 3), and the pass only selects which plane the
+  // staging addresses point at (the hi tiles are fetched twice back to back: the second fetch hits L2).
+  FLAG_SPLIT = 2,
 };
 
 template <int N>
@@ -170,11 +182,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   const int m0 = (tm % tpb) * BM;
   const int n0 = tn * BN;
   const int N = p.N, K = p.K;
-  const int nkt_all = K / BK;
+  constexpr bool X3 = (FLAGS & FLAG_SPLIT) != 0;
+  const int nkt_all = X3 ? 3 * (K / BK) : K / BK;
   // K range of this block (even split; skewing the ranges so that the producer finishes early did not
   // pay: the release fence of the early block slows the L2 for the blocks still in their main loop)
   const int kbase = (int)((long long)sidx * nkt_all / S);
   const int nkt = (int)((long long)(sidx + 1) * nkt_all / S) - kbase;
+
+  // logical K-step kt of this block -> operand K-step; FLAG_SPLIT: also the byte offsets that move the activation /
+  // weight source to its lo plane for this pass (pass 0: hi*hi, 1: hi*lo, 2: lo*hi).  All wave-uniform.
+  auto kstep = [&](int kt, long long& a_adj, long long& w_adj) {
+    const int g = kt + kbase;
+    if constexpr (X3) {
+      const int kk = g / 3, pass = g - kk * 3;
+      a_adj = pass == 2 ? p.a_lo * 2 : 0;
+      w_adj = pass == 1 ? p.w_lo * 2 : 0;
+      return kk;
+    } else {
+      a_adj = 0;
+      w_adj = 0;
+      return g;
+    }
+  };
 
   // ---- per-lane staging sources ----------------------------------------------
   const int lr = lane >> 3;             // row inside an 8-row piece
@@ -246,22 +275,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   // [i0, i1) = the subset of this wave's pieces to issue (PIPE 4 spreads them between MFMAs)
   auto stage_a = [&](int kt, int slot, int i0 = 0, int i1 = 64) {
     char* sa = smem + slot * A_BYTES;
+    long long a_adj, w_adj_unused;
+    const int ks = kstep(kt, a_adj, w_adj_unused);
     if (AMODE == 0) {
 #pragma unroll
       for (int i = 0; i < APW; ++i)
-        if (i >= i0 && i < i1) glds16(asrc[i] + (long long)(kt + kbase) * (BK * 2), sa + (wave + i * NWAVES) * 1024);
+        if (i >= i0 && i < i1) glds16(asrc[i] + (long long)ks * (BK * 2) + a_adj, sa + (wave + i * NWAVES) * 1024);
     } else {
       // K order = channel chunk outer, filter tap inner: the 9 taps of one 64-channel chunk are
       // staged back to back, so their overlapping input rows are still in L1/L2 (a tap-major order
       // re-streams the whole input tile 9 times through the XCD's L2).
       const int ntap = p.cv.ksize * p.cv.ksize;
-      const int cch = (kt + kbase) / ntap;
-      const int tap = (kt + kbase) - cch * ntap;
+      const int cch = ks / ntap;
+      const int tap = ks - cch * ntap;
       const int c0 = cch << 6;
       const int dy = (p.cv.ksize == 3) ? tap / 3 : 0;
       const int dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
       if (!p.cv.ups) {
-        const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2;   // wave-uniform
+        const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj;   // wave-uniform
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
           if (i < i0 || i >= i1) continue;
@@ -280,7 +311,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
         bool ok = (yy >= 0) & (yy < Hl) & (xx >= 0) & (xx < Wl);
         uint32_t img = cimg[i];
         asm volatile("" : "+v"(img));
-        const char* src = ok ? cX + (long long)img * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2
+        const char* src = ok ? cX + (long long)img * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2 + a_adj
                              : (const char*)p.cv.zero;
         glds16(src, sa + (wave + i * NWAVES) * 1024);
       }
@@ -288,15 +319,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   };
   auto stage_w = [&](int kt, int slot, int i0 = 0, int i1 = 64) {
     char* sb = smem + W_BASE + slot * B_BYTES;
-    int koff = (kt + kbase) * BK;            // K offset (elements) of this step inside a W row
+    long long a_adj_unused, w_adj;
+    const int ks = kstep(kt, a_adj_unused, w_adj);
+    int koff = ks * BK;                      // K offset (elements) of this step inside a W row
     if (AMODE == 1) {                        // conv: weight column = tap*Cin + c0 (pure index remap)
       const int ntap = p.cv.ksize * p.cv.ksize;
-      const int cch = (kt + kbase) / ntap;
-      koff = ((kt + kbase) - cch * ntap) * p.cv.Cin + (cch << 6);
+      const int cch = ks / ntap;
+      koff = (ks - cch * ntap) * p.cv.Cin + (cch << 6);
     }
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
-      if (i >= i0 && i < i1) glds16(bsrc[i] + (long long)koff * 2, sb + min(wave + i * NWAVES, BPIECES - 1) * 1024);
+      if (i >= i0 && i < i1) glds16(bsrc[i] + (long long)koff * 2 + w_adj, sb + min(wave + i * NWAVES, BPIECES - 1) * 1024);
   };
 
   // ---- fragment read offsets (same XOR as the staging source swizzle) ---------
@@ -445,10 +478,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
         }
         auto stage = [&](int kt, int slot) {       // A(kt) -> activation slot `slot`
           int tap = 0, c0 = 0, dy = 0, dx = 0;
+          long long a_adj, w_adj_unused;
+          const int ks = kstep(kt, a_adj, w_adj_unused);
           if (AMODE == 1) {                        // K order: channel chunk outer, filter tap inner
             const int ntap = p.cv.ksize * p.cv.ksize;
-            const int cch = (kt + kbase) / ntap;
-            tap = (kt + kbase) - cch * ntap;
+            const int cch = ks / ntap;
+            tap = ks - cch * ntap;
             c0 = cch << 6;
             dy = (p.cv.ksize == 3) ? tap / 3 : 0;
             dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
@@ -457,14 +492,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
           for (int i = 0; i < PA; ++i) {
             const char* s_ = nullptr;
             if (AMODE == 0) {
-              s_ = src[i] + (long long)(kt + kbase) * (BK * 2);
+              s_ = src[i] + (long long)ks * (BK * 2) + a_adj;
             } else if (!p.cv.ups) {
-              const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2;
+              const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj;
               s_ = ((gyx[i] >> tap) & 1) ? cX + (long long)(int)gimg[i] * 16 + uoff : (const char*)p.cv.zero;
             } else {
               const int yy = (gyx[i] >> 16) + dy, xx = (int)(short)(gyx[i] & 0xffff) + dx;
               const bool ok = (yy >= 0) & (yy < p.cv.Hs * 2) & (xx >= 0) & (xx < p.cv.Ws * 2);
-              s_ = ok ? cX + (long long)gimg[i] * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2
+              s_ = ok ? cX + (long long)gimg[i] * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2 + a_adj
                       : (const char*)p.cv.zero;
             }
             glds16(s_, smem + slot * A_BYTES + (lw + i * LW) * 1024);
@@ -509,12 +544,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
           src[i] = (const char*)(gW + (long long)b * w_bs + (long long)min(n0 + row, N - 1) * K) + lc * 16;
         }
         auto stage = [&](int kt, int slot) {       // W(kt) -> weight slot `slot`
-          long long koff = (long long)(kt + kbase) * (BK * 2);
+          long long a_adj_unused, w_adj;
+          const int ks = kstep(kt, a_adj_unused, w_adj);
+          long long koff = (long long)ks * (BK * 2);
           if (AMODE == 1) {
             const int ntap = p.cv.ksize * p.cv.ksize;
-            const int cch = (kt + kbase) / ntap;
-            koff = ((long long)((kt + kbase) - cch * ntap) * p.cv.Cin + (cch << 6)) * 2;
+            const int cch = ks / ntap;
+            koff = ((long long)(ks - cch * ntap) * p.cv.Cin + (cch << 6)) * 2;
           }
+          koff += w_adj;
 #pragma unroll
           for (int i = 0; i < PB; ++i)
             glds16(src[i] + koff, smem + W_BASE + slot * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
@@ -758,6 +796,47 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   // The direct path remains for float32 outputs and for operands that are not 16-byte aligned.
   const int epi = p.epi;
   const float alpha = p.alpha;
+  if constexpr (X3) {
+    // FLAG_SPLIT epilogue: v = alpha * acc + bias (float32 bias, by column or by row) [+ residual (hi + lo planes)],
+    // then either float32 out (attention logits) or the hi / lo bf16 planes of v.  Direct stores from the MFMA
+    // layout (8 bytes per lane and plane): the 3-pass main loop is three times as long as the bf16 one, so the
+    // store tail weighs a third of what it does there.
+    const float* fbias = (const float*)gBias;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + r16;
+      if (m >= Mg) continue;
+      const float rb = (fbias && p.row_bias) ? fbias[m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
+        if (n4 >= N) continue;
+        f32x4 v = acc[i][j] * alpha;
+        if (fbias && !p.row_bias) v += *(const f32x4*)(fbias + n4);
+        v += rb;
+        const long long idx = (long long)b * c_bs + (long long)m * p.ldc + n4;
+        if (p.out_f32) {
+          *(f32x4*)((float*)gC + idx) = v;
+          continue;
+        }
+        if (epi == EPI_GATE_RES) {
+          const u32x2 rh = *(const u32x2*)(gRes + idx), rl = *(const u32x2*)(gRes + idx + p.res_lo);
+          v[0] += bf_lo(rh[0]) + bf_lo(rl[0]);
+          v[1] += bf_hi(rh[0]) + bf_hi(rl[0]);
+          v[2] += bf_lo(rh[1]) + bf_lo(rl[1]);
+          v[3] += bf_hi(rh[1]) + bf_hi(rl[1]);
+        }
+        u32x2 oh, ol;
+        oh[0] = pack_bf16x2(v[0], v[1]);
+        oh[1] = pack_bf16x2(v[2], v[3]);
+        ol[0] = pack_bf16x2(v[0] - bf_lo(oh[0]), v[1] - bf_hi(oh[0]));
+        ol[1] = pack_bf16x2(v[2] - bf_lo(oh[1]), v[3] - bf_hi(oh[1]));
+        *(u32x2*)(gC + idx) = oh;
+        *(u32x2*)(gC + idx + p.c_lo) = ol;
+      }
+    }
+    return;
+  }
   constexpr int NCH = WTN / 8;                      // 16-byte chunks per row of the wave's sub-tile
   const bool wide = p.wide_epi != 0;
   char* const my_lds = smem + wave * (WTM * WTN * 2);

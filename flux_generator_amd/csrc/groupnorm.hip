@@ -14,11 +14,30 @@
 
 namespace {
 
+// 8 channels of one pixel as float32: a bf16 chunk, or (SPLIT) the sum of the hi and lo plane chunks
+template <bool SPLIT>
+DEVINL void load8(const bf16_t* p, long long lo_off, float (&v)[8]) {
+  const u32x4 h = *(const u32x4*)p;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[2 * e] = bf_lo(h[e]);
+    v[2 * e + 1] = bf_hi(h[e]);
+  }
+  if constexpr (SPLIT) {
+    const u32x4 l = *(const u32x4*)(p + lo_off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] += bf_lo(l[e]);
+      v[2 * e + 1] += bf_hi(l[e]);
+    }
+  }
+}
+
 // CB = channel chunks (of 8 channels) handled per block along blockIdx.z; 256 % CB == 0
-template <int CB>
+template <int CB, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x,
                                                          float* __restrict__ ws, int HW, int C,
-                                                         int nchunks, int ppb) {
+                                                         int nchunks, int ppb, long long x_lo = 0) {
   constexpr int ROWS = 256 / CB;
   __shared__ float red[256][17];
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -32,19 +51,23 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
   constexpr int U = 4;
   for (int p = p0 + prow; p < p1; p += ROWS * U) {
-    u32x4 w[U];
+    float w[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int pp = p + u * ROWS;
-      w[u] = pp < p1 ? *((const u32x4*)(x + ((long long)b * HW + pp) * C) + cc) : u32x4{0, 0, 0, 0};
+      if (pp < p1) {
+        load8<SPLIT>(x + ((long long)b * HW + pp) * C + cc * 8, x_lo, w[u]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[u][e] = 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = bf_lo(w[u][e]), c = bf_hi(w[u][e]);
-        s[2 * e] += a; q[2 * e] += a * a;
-        s[2 * e + 1] += c; q[2 * e + 1] += c * c;
+      for (int e = 0; e < 8; ++e) {
+        s[e] += w[u][e];
+        q[e] += w[u][e] * w[u][e];
       }
   }
 #pragma unroll
@@ -105,13 +128,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(float* __restrict__ ws
   }
 }
 
-template <int CB>
+// SPLIT: x / out are hi+lo plane pairs, gamma / beta are float32
+template <int CB, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x,
                                                        const float* __restrict__ ws,
                                                        const bf16_t* __restrict__ gamma,
                                                        const bf16_t* __restrict__ beta,
                                                        bf16_t* __restrict__ out, int HW, int C, int G,
-                                                       int nchunks, int silu, int ppb) {
+                                                       int nchunks, int silu, int ppb, long long x_lo = 0,
+                                                       long long out_lo = 0) {
   constexpr int ROWS = 256 / CB;
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -125,43 +150,58 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   const int cc = blockIdx.z * CB + (tid % CB);
   const int prow = tid / CB;
   const int cg = C / G;
-  u32x4 gw = *((const u32x4*)gamma + cc);
-  u32x4 bw = *((const u32x4*)beta + cc);
+  float gaf[8], bef[8];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gaf[e] = ((const float*)gamma)[cc * 8 + e];
+      bef[e] = ((const float*)beta)[cc * 8 + e];
+    }
+  } else {
+    const u32x4 gw = *((const u32x4*)gamma + cc);
+    const u32x4 bw = *((const u32x4*)beta + cc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gaf[e] = (e & 1) ? bf_hi(gw[e >> 1]) : bf_lo(gw[e >> 1]);
+      bef[e] = (e & 1) ? bf_hi(bw[e >> 1]) : bf_lo(bw[e >> 1]);
+    }
+  }
   float fa[8], fc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int g = (cc * 8 + e) / cg;
-    const float ga = (e & 1) ? bf_hi(gw[e >> 1]) : bf_lo(gw[e >> 1]);
-    const float be = (e & 1) ? bf_hi(bw[e >> 1]) : bf_lo(bw[e >> 1]);
-    fa[e] = s_rstd[g] * ga;
-    fc[e] = be - s_mean[g] * fa[e];
+    fa[e] = s_rstd[g] * gaf[e];
+    fc[e] = bef[e] - s_mean[g] * fa[e];
   }
   const int p0 = chunk * ppb;
   const int p1 = min(p0 + ppb, HW);
   constexpr int U = 4;
   for (int p = p0 + prow; p < p1; p += ROWS * U) {
-    u32x4 w[U];
+    float w[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int pp = min(p + u * ROWS, p1 - 1);
-      w[u] = *((const u32x4*)(x + ((long long)b * HW + pp) * C) + cc);
+      load8<SPLIT>(x + ((long long)b * HW + pp) * C + cc * 8, x_lo, w[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int pp = p + u * ROWS;
       if (pp >= p1) break;
-      u32x4 o;
+      u32x4 o, ol;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float y0 = fmaf(bf_lo(w[u][e]), fa[2 * e], fc[2 * e]);
-        float y1 = fmaf(bf_hi(w[u][e]), fa[2 * e + 1], fc[2 * e + 1]);
+        float y0 = fmaf(w[u][2 * e], fa[2 * e], fc[2 * e]);
+        float y1 = fmaf(w[u][2 * e + 1], fa[2 * e + 1], fc[2 * e + 1]);
         if (silu) {
-          y0 = silu_f(y0);
-          y1 = silu_f(y1);
+          y0 = SPLIT ? y0 / (1.0f + expf(-y0)) : silu_f(y0);       // fp32-faithful path: full-precision exp
+          y1 = SPLIT ? y1 / (1.0f + expf(-y1)) : silu_f(y1);
         }
         o[e] = pack_bf16x2(y0, y1);
+        if constexpr (SPLIT) ol[e] = pack_bf16x2(y0 - bf_lo(o[e]), y1 - bf_hi(o[e]));
       }
-      *((u32x4*)(out + ((long long)b * HW + pp) * C) + cc) = o;
+      bf16_t* dst = out + ((long long)b * HW + pp) * C + cc * 8;
+      *(u32x4*)dst = o;
+      if constexpr (SPLIT) *(u32x4*)(dst + out_lo) = ol;
     }
   }
 }
@@ -199,5 +239,38 @@ extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, con
   else if (cb == 16) GN_RUN(16);
   else GN_RUN(8);
 #undef GN_RUN
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_groupnorm_silu_x3(const void* x, int64_t x_lo, const void* gamma, const void* beta,
+                                         void* out, int64_t out_lo, int B, int HW, int C, int G, float eps,
+                                         int silu, void* ws, int64_t ws_bytes, void* stream) {
+  if (!x || !gamma || !beta || !out || !ws) return FLUXHIP_EINVAL;
+  if (B < 1 || HW < 1 || C % 8 || G < 1 || G > 64 || C % G || (x_lo | out_lo) % 8) return FLUXHIP_EINVAL;
+  const int cpr = C / 8;
+  const int cb = cpr % 64 == 0 ? 64 : cpr % 32 == 0 ? 32 : cpr % 16 == 0 ? 16 : cpr % 8 == 0 ? 8 : 0;
+  if (!cb) return FLUXHIP_EINVAL;
+  int ppb = 1024;
+  while (ppb > 32 && (long long)B * ((HW + ppb - 1) / ppb) * (cpr / cb) < 512) ppb >>= 1;
+  const int nchunks = (HW + ppb - 1) / ppb;
+  if (ws_bytes < ((int64_t)B * nchunks * C + (int64_t)B * G) * 2 * (int64_t)sizeof(float))
+    return FLUXHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(nchunks, B, cpr / cb), block(256);
+#define GN_RUN3(CB)                                                                                  \
+  do {                                                                                               \
+    hipLaunchKernelGGL((gn_partial_kernel<CB, true>), grid, block, 0, s, (const bf16_t*)x,           \
+                       (float*)ws, HW, C, nchunks, ppb, (long long)x_lo);                            \
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(256), 0, s, (float*)ws, B, C, G,         \
+                       nchunks, (float)HW * (float)(C / G), eps);                                    \
+    hipLaunchKernelGGL((gn_apply_kernel<CB, true>), grid, block, 0, s, (const bf16_t*)x,             \
+                       (const float*)ws, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)out,    \
+                       HW, C, G, nchunks, silu, ppb, (long long)x_lo, (long long)out_lo);            \
+  } while (0)
+  if (cb == 64) GN_RUN3(64);
+  else if (cb == 32) GN_RUN3(32);
+  else if (cb == 16) GN_RUN3(16);
+  else GN_RUN3(8);
+#undef GN_RUN3
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }

@@ -6,20 +6,20 @@ conv's epilogue, GroupNorm+SiLU as a two-launch HBM-bound pair, and the single-h
 AttnBlock as QK^T / softmax / PV GEMMs.  Encoder / DiagonalGaussian (training, img2img) are out
 of the hot-path scope.
 
-Precision note: the reference runs this decoder in fp32 (checkpoint dtype).  Here weights and
-activations are bf16 with fp32 accumulation and fp32 GroupNorm/softmax statistics; the tolerance of
-that deliberate change is stated in tests/test_vae_gpu.py.
+Precision: the reference runs this decoder in fp32 (checkpoint dtype, flux/utils.py:137-143).  The default
+here is the fp32-faithful split-bf16 path (3 MFMA passes per product, fp32 accumulation / norms / softmax);
+a bf16-storage mode remains as an opt-in.  Tolerances of both are stated in tests/test_vae_gpu.py.
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
-from typing import Dict, Iterable, List, Tuple, Union
+from typing import Dict, Iterable, List, Optional, Tuple, Union
 
 import torch
 
 from .. import _lib, ops
-from ..ops import EPI_BIAS, EPI_GATE_RES, FluxHipError, make_gemm_desc
+from .. import vae_common as V
+from ..ops import FluxHipError
 
 BF16 = torch.bfloat16
 
@@ -82,30 +82,28 @@ def decoder_weight_shapes(A: AutoEncoderParams) -> Dict[str, Tuple[int, ...]]:
 
 
 class AutoEncoder:
-    def __init__(self, params: AutoEncoderParams, device: Union[str, torch.device] = "cuda"):
+    """precision = "fp32" (default) is the reference's arithmetic, run on the fp32-faithful split-bf16 kernels;
+    "bf16" is the bf16-storage opt-in (see vae_common.py)."""
+
+    def __init__(self, params: AutoEncoderParams, device: Union[str, torch.device] = "cuda", precision: str = "fp32"):
+        V.check_precision(precision)
         self.params = params
         self.scale_factor = params.scale_factor
         self.shift_factor = params.shift_factor
+        self.precision = precision
         if torch.device(device).type != "cuda":
             raise FluxHipError("AutoEncoder needs a HIP device: there is no CPU fallback for the decode path")
         self.device = _lib.bind_device(device)
         _lib.load()
-        self._params = {k: torch.empty(*shp, dtype=BF16, device=self.device)
-                        for k, shp in decoder_weight_shapes(params).items()}
+        # conv_in's 16 input channels are zero-padded to the implicit-GEMM loader's 64-channel K-step (exact)
+        self._store = V.ParamStore(decoder_weight_shapes(params), self.device, pad64=("decoder.conv_in.weight",))
 
     def parameters(self) -> Dict[str, torch.Tensor]:
-        return self._params
+        """float32 master parameters (the checkpoint's dtype)."""
+        return self._store.master
 
     def init_random(self, seed: int = 0) -> "AutoEncoder":
-        g = torch.Generator(device=self.device).manual_seed(seed)
-        for name, t in self._params.items():
-            base = name.rsplit(".", 1)[0]
-            wt = self._params[f"{base}.weight"]
-            if wt.dim() == 1:       # GroupNorm affine
-                t.fill_(1.0 if name.endswith(".weight") else 0.0)
-                continue
-            k = 1.0 / math.sqrt(wt[0].numel())
-            t.copy_(((torch.rand(t.shape, generator=g, device=self.device) * 2 - 1) * k).to(BF16))
+        self._store.init_random(seed)
         return self
 
     def sanitize(self, weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -122,105 +120,55 @@ class AutoEncoder:
 
     def load_weights(self, weights: Union[Dict[str, torch.Tensor], Iterable[Tuple[str, torch.Tensor]]],
                      strict: bool = True) -> "AutoEncoder":
-        items = weights.items() if isinstance(weights, dict) else weights
-        seen = set()
-        for k, w in items:
-            if k not in self._params:
-                if k.startswith("encoder.") or not strict:
-                    continue        # the encoder is not part of the decode hot path
-                raise ValueError(f"Unexpected parameter {k}")
-            dst = self._params[k]
-            if tuple(dst.shape) != tuple(w.shape):
-                raise ValueError(f"Shape mismatch for {k}: expected {tuple(dst.shape)}, got {tuple(w.shape)}")
-            dst.copy_(w.to(device=self.device, dtype=BF16))
-            seen.add(k)
-        if strict and set(self._params) - seen:
-            raise ValueError(f"Missing parameters: {sorted(set(self._params) - seen)[:5]} ...")
+        self._store.load(weights, strict, skip_prefixes=("encoder.",))     # the encoder is not on the decode path
         return self
 
-    # ------------------------------------------------------------------ blocks
-    def _resnet(self, p: str, x: torch.Tensor) -> torch.Tensor:
+    # ------------------------------------------------------------------ blocks (x: bf16 NHWC, or split [2,B,H,W,C])
+    def _resnet(self, p: str, x: torch.Tensor, fp32: bool = False) -> torch.Tensor:
         """ResnetBlock.__call__ (flux/autoencoder.py:83-98)."""
-        W = self._params
-        h = ops.groupnorm_silu(x, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], 32, 1e-6, True)
-        h = ops.conv2d(h, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"])
-        h = ops.groupnorm_silu(h, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], 32, 1e-6, True)
-        if f"{p}.nin_shortcut.weight" in W:
-            x = ops.conv2d(x, W[f"{p}.nin_shortcut.weight"], W[f"{p}.nin_shortcut.bias"])
-        return ops.conv2d(h, W[f"{p}.conv2.weight"], W[f"{p}.conv2.bias"], res=x)
+        return V.resnet(self._store, fp32, p, x, "nin_shortcut", 32, 1e-6)
 
-    def _attn(self, p: str, x: torch.Tensor) -> torch.Tensor:
+    def _attn(self, p: str, x: torch.Tensor, fp32: bool = False) -> torch.Tensor:
         """AttnBlock.__call__ (flux/autoencoder.py:42-52): one 512-wide head over H*W tokens."""
-        W = self._params
-        B, H, Wd, C = x.shape
-        N = H * Wd
-        y = ops.groupnorm_silu(x, W[f"{p}.norm.weight"], W[f"{p}.norm.bias"], 32, 1e-6, False)
-        q = ops.linear(y.view(B, N, C), W[f"{p}.q.weight"], W[f"{p}.q.bias"])
-        k = ops.linear(y.view(B, N, C), W[f"{p}.k.weight"], W[f"{p}.k.bias"])
-        out = torch.empty_like(x)
-        Np = (N + 63) // 64 * 64      # the PV contraction runs over Np keys (zero padded)
-        vt = torch.zeros(C, Np, dtype=BF16, device=x.device)
-        s = torch.empty(N, Np, dtype=torch.float32, device=x.device)
-        pm = torch.zeros(N, Np, dtype=BF16, device=x.device)
-        o = torch.empty(N, C, dtype=BF16, device=x.device)
-        for b in range(B):
-            yb, qb, kb = y[b].view(N, C), q[b], k[b]
-            # V^T[C,N] = Wv y^T + bv (row bias): the PV product then needs no transpose
-            ops.gemm(make_gemm_desc([dict(A=W[f"{p}.v.weight"].data_ptr(), W=yb.data_ptr(), bias=W[f"{p}.v.bias"].data_ptr(),
-                                          C=vt.data_ptr(), M=C)], 1, N, C, C, Np, EPI_BIAS, row_bias=True))
-            ops.gemm(make_gemm_desc([dict(A=qb.data_ptr(), W=kb.data_ptr(), C=s.data_ptr(), M=N)], 1, N, C, C, Np,
-                                    EPI_BIAS, out_f32=True))
-            ops.softmax_rows(s, C ** -0.5, out=pm, cols=N)
-            ops.gemm(make_gemm_desc([dict(A=pm.data_ptr(), W=vt.data_ptr(), C=o.data_ptr(), M=N)], 1, C, Np, Np, C))
-            ops.linear(o, W[f"{p}.proj_out.weight"], W[f"{p}.proj_out.bias"], epi=EPI_GATE_RES,
-                       out=out[b].view(N, C), res=x[b].view(N, C))
-        return out
+        return V.attention(self._store, fp32, p, x, "norm", "q", "k", "v", "proj_out", 32, 1e-6)
 
-    def _conv_in(self, z: torch.Tensor) -> torch.Tensor:
-        """decoder.conv_in (16 -> 512 channels).  16 input channels are below the implicit-GEMM loader's
-        64-channel K-step, so z and the weight are zero-padded to 64 channels (exact: the extra products are 0)
-        and the layer runs on the MFMA path like every other conv."""
-        W = self._params
-        w = W["decoder.conv_in.weight"]
-        cin = w.shape[-1]
-        if cin % 64 == 0:
-            return ops.conv2d(z, w, W["decoder.conv_in.bias"])
-        pad = 64 - cin % 64
-        key = (w.data_ptr(), w._version)
-        if getattr(self, "_conv_in_key", None) != key:
-            self._conv_in_w = torch.nn.functional.pad(w, (0, pad)).contiguous()
-            self._conv_in_key = key
-        return ops.conv2d(torch.nn.functional.pad(z, (0, pad)), self._conv_in_w, W["decoder.conv_in.bias"])
-
-    def _decoder(self, z: torch.Tensor, clip01: bool) -> torch.Tensor:
-        """Decoder.__call__ (flux/autoencoder.py:271-297). z NHWC bf16 -> float32 NHWC image."""
-        A, W = self.params, self._params
+    def _decoder(self, z: torch.Tensor, clip01: bool, fp32: bool) -> torch.Tensor:
+        """Decoder.__call__ (flux/autoencoder.py:271-297). z (64 channels, zero padded) -> float32 NHWC image."""
+        A, S = self.params, self._store
         nres = len(A.ch_mult)
-        h = self._conv_in(z)
-        h = self._resnet("decoder.mid.block_1", h)
-        h = self._attn("decoder.mid.attn_1", h)
-        h = self._resnet("decoder.mid.block_2", h)
+        h = V.conv(S, fp32, "decoder.conv_in", z)
+        h = self._resnet("decoder.mid.block_1", h, fp32)
+        h = self._attn("decoder.mid.attn_1", h, fp32)
+        h = self._resnet("decoder.mid.block_2", h, fp32)
         for lvl in reversed(range(nres)):
             for i in range(A.num_res_blocks + 1):
-                h = self._resnet(f"decoder.up.{lvl}.block.{i}", h)
+                h = self._resnet(f"decoder.up.{lvl}.block.{i}", h, fp32)
             if lvl != 0:   # Upsample: nearest x2 fused into the conv loader (flux/autoencoder.py:120-123)
-                h = ops.conv2d(h, W[f"decoder.up.{lvl}.upsample.conv.weight"], W[f"decoder.up.{lvl}.upsample.conv.bias"],
-                               ups=True)
-        h = ops.groupnorm_silu(h, W["decoder.norm_out.weight"], W["decoder.norm_out.bias"], 32, 1e-6, True)
-        return ops.conv2d_out_image(h, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clip01)
+                h = V.conv(S, fp32, f"decoder.up.{lvl}.upsample.conv", h, ups=True)
+        return V.norm_out_conv_out(S, fp32, "decoder.norm_out", "decoder.conv_out", h, 32, 1e-6, clip01)
 
     # ------------------------------------------------------------------ public surface
-    def decode(self, z: torch.Tensor) -> torch.Tensor:
+    def _cpad(self) -> int:
+        return (self.params.z_channels + 63) // 64 * 64
+
+    def decode(self, z: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
         """AutoEncoder.decode (flux/autoencoder.py:352-354): z [B,h,w,16] -> [B,8h,8w,3] float32."""
         z = z.to(BF16).contiguous()
-        B, h, w, c = z.shape
-        # z / scale_factor + shift_factor rides on the unpack kernel (pack then unpack = identity permutation)
-        zz = ops.unpack_latents(ops.pack_latents(z), h, w, self.scale_factor, self.shift_factor)
-        return self._decoder(zz, clip01=False)
+        _, h, w, _ = z.shape
+        return self.decode_packed(ops.pack_latents(z), (h, w), precision, clip01=False)
 
-    def decode_packed(self, x: torch.Tensor, latent_size: Tuple[int, int]) -> torch.Tensor:
+    def decode_packed(self, x: torch.Tensor, latent_size: Tuple[int, int], precision: Optional[str] = None,
+                      clip01: bool = True) -> torch.Tensor:
         """FluxPipeline.decode fused (flux/flux.py:157-162): packed latents [B,L,64] ->
-        clip(decode(unpack(x)) + 1, 0, 2) * 0.5, float32 NHWC in [0,1]."""
+        clip(decode(unpack(x)) + 1, 0, 2) * 0.5, float32 NHWC in [0,1].  z / scale_factor + shift_factor
+        (flux/autoencoder.py:353) rides on the unpack kernel."""
+        V.check_precision(precision)
         h, w = latent_size
-        z = ops.unpack_latents(x.to(BF16).contiguous(), h, w, self.scale_factor, self.shift_factor)
-        return self._decoder(z, clip01=True)
+        x = x.to(BF16).contiguous()
+        if (precision or self.precision) == "fp32":
+            z = ops.unpack_latents_x3(x, h, w, self.scale_factor, self.shift_factor, self._cpad())
+            return self._decoder(z, clip01, True)
+        z = ops.unpack_latents(x, h, w, self.scale_factor, self.shift_factor)
+        if z.shape[-1] % 64:
+            z = ops.concat_channels(z, None, pad_to=self._cpad())
+        return self._decoder(z, clip01, False)

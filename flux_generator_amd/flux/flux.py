@@ -177,23 +177,25 @@ class FluxPipeline:
         it is just the uint8 conversion."""
         return parallel.gather_images(parallel.to_uint8(images).contiguous(), n_images)
 
-    def decode(self, x: torch.Tensor, latent_size: Tuple[int, int] = (64, 64)) -> torch.Tensor:
+    def decode(self, x: torch.Tensor, latent_size: Tuple[int, int] = (64, 64), precision: Optional[str] = None) -> torch.Tensor:
         """flux/flux.py:157-162: [b,L,64] -> [b,8h,8w,3] float in [0,1] (unpack, VAE decode, clip fused).
-        With use_graph the ~150 launches of a decode are captured once per shape and replayed."""
+        The decode runs in the reference's float32 arithmetic (AutoEncoder precision "fp32", the default) unless
+        precision="bf16" is asked for.  With use_graph the ~200 launches of a decode are captured once per shape."""
+        precision = precision or self.ae.precision
         if not self.use_graph:
-            return self.ae.decode_packed(x, latent_size)
-        key = ("decode", x.shape[0], tuple(latent_size))
+            return self.ae.decode_packed(x, latent_size, precision)
+        key = ("decode", x.shape[0], tuple(latent_size), precision)
         ent = self._graphs.get(key)
         if ent is None:
             static_in = x.to(self.dtype).contiguous().clone()
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self.ae.decode_packed(static_in, latent_size)      # warm-up (attribute calls, workspaces)
+                self.ae.decode_packed(static_in, latent_size, precision)      # warm-up (attribute calls, workspaces)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                static_out = self.ae.decode_packed(static_in, latent_size)
+                static_out = self.ae.decode_packed(static_in, latent_size, precision)
             ent = (g, static_in, static_out)
             self._graphs[key] = ent
         g, static_in, static_out = ent

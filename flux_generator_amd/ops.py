@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import GemmDesc
+from ._lib import GemmDesc, GemmX3Desc
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU, EPI_QUICK_GELU = 0, 1, 2, 3, 4, 5, 6
 BF16 = torch.bfloat16
@@ -250,6 +250,157 @@ def softmax_rows(s: torch.Tensor, scale: float, out: Optional[torch.Tensor] = No
         out = torch.zeros(s.shape, dtype=BF16, device=s.device)
     _check(_lib.load().fluxhip_softmax_rows_f32(_p(s), _p(out), rows, cols, ld, float(scale), _stream()),
            "fluxhip_softmax_rows_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ fp32-faithful VAE path
+# A "split tensor" is a bf16 tensor of shape [2, ...]: plane 0 = hi = bf16(x), plane 1 = lo = bf16(x - hi), so that
+# x = hi + lo to 2^-17 relative (include/fluxhip.h, "bf16x3").  Views that keep dim 0 (t[:, b]) stay split tensors.
+F32 = torch.float32
+
+
+def _split_ok(t: torch.Tensor, name: str) -> None:
+    if t.dtype != BF16 or t.dim() < 2 or t.shape[0] != 2 or not t[0].is_contiguous() or not t.is_cuda:
+        raise FluxHipError(f"{name} must be a split tensor: bf16 [2, ...] with contiguous planes on the device")
+
+
+def _f32c(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
+    if t is not None and (t.dtype != F32 or not t.is_contiguous()):
+        raise FluxHipError(f"{name} must be a contiguous float32 tensor")
+    return t
+
+
+def split_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float32 [...] -> split tensor [2, ...]."""
+    _f32c(x, "x")
+    if out is None:
+        out = torch.empty(2, *x.shape, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_split_f32(_p(x), _p(out[0]), _p(out[1]), x.numel(), _stream()), "fluxhip_split_f32")
+    return out
+
+
+def join_f32(t: torch.Tensor) -> torch.Tensor:
+    """split tensor [2, ...] -> float32 [...] (hi + lo)."""
+    _split_ok(t, "t")
+    out = torch.empty(t.shape[1:], dtype=F32, device=t.device)
+    _check(_lib.load().fluxhip_join_f32(_p(t[0]), _p(t[1]), _p(out), out.numel(), _stream()), "fluxhip_join_f32")
+    return out
+
+
+def gemm_x3(A: torch.Tensor, W: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, lda: int, ldc: int,
+            bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, row_bias: bool = False,
+            alpha: float = 1.0, out_f32: bool = False, tile_cfg: int = 0) -> None:
+    """C = alpha * A W^T + bias [+ res] in the fp32-faithful mode.  A [2][M][lda], W [2][N][K] split; C split
+    [2][M][ldc] or float32 [M][ldc] (out_f32); bias float32."""
+    _split_ok(A, "A"); _split_ok(W, "W")
+    d = GemmX3Desc()
+    d.A, d.W, d.bias, d.res = _p(A[0]), _p(W[0]), _p(_f32c(bias, "bias")), (_p(res[0]) if res is not None else None)
+    d.a_lo, d.w_lo = A.stride(0), W.stride(0)
+    if out_f32:
+        _f32c(C, "C")
+        d.C, d.c_lo = _p(C), 0
+    else:
+        _split_ok(C, "C")
+        d.C, d.c_lo = _p(C[0]), C.stride(0)
+    if res is not None:
+        _split_ok(res, "res")
+        d.res_lo = res.stride(0)
+    d.M, d.nbatch, d.N, d.K, d.lda, d.ldc = M, 1, N, K, lda, ldc
+    d.epi, d.row_bias, d.out_f32, d.tile_cfg, d.alpha = (EPI_GATE_RES if res is not None else EPI_BIAS), int(row_bias), \
+        int(out_f32), tile_cfg, alpha
+    _check(_lib.load().fluxhip_gemm_x3(d, _stream()), "fluxhip_gemm_x3")
+
+
+def linear_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], res: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear in float32 on split tensors: x [2, ..., K], w [2, N, K], b float32 [N]; res adds a split residual."""
+    K, N = x.shape[-1], w.shape[1]
+    M = x[0].numel() // K
+    if out is None:
+        out = torch.empty(2, *x.shape[1:-1], N, dtype=BF16, device=x.device)
+    gemm_x3(x, w, out, M, N, K, K, N, bias=b, res=res)
+    return out
+
+
+def conv2d_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], stride: int = 1, pad: int = 1, ups: bool = False,
+              res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC conv in float32 on split tensors: x [2,B,H,W,Cin], w [2,Cout,kh,kw,Cin] (or [2,Cout,Cin]), b float32."""
+    _split_ok(x, "x"); _split_ok(w, "w")
+    _, B, Hs, Ws, Cin = x.shape
+    Cout = w.shape[1]
+    ks = 1 if w.dim() == 3 else w.shape[2]
+    if ks == 1:
+        pad = 0
+    Hl, Wl = (Hs * 2, Ws * 2) if ups else (Hs, Ws)
+    Ho, Wo = (Hl + 2 * pad - ks) // stride + 1, (Wl + 2 * pad - ks) // stride + 1
+    if out is None:
+        out = torch.empty(2, B, Ho, Wo, Cout, dtype=BF16, device=x.device)
+    if res is not None:
+        _split_ok(res, "res")
+    _check(_lib.load().fluxhip_conv2d_x3(_p(x[0]), x.stride(0), _p(w[0]), w.stride(0), _p(_f32c(b, "bias")),
+                                         _p(res[0]) if res is not None else None, res.stride(0) if res is not None else 0,
+                                         _p(out[0]), out.stride(0), B, Hs, Ws, Cin, Cout, ks, stride, pad, int(ups),
+                                         _p(_zeros16(x.device)), _stream()), "fluxhip_conv2d_x3")
+    return out
+
+
+def groupnorm_silu_x3(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6,
+                      silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _split_ok(x, "x")
+    _, B, H, W_, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    ws = _gn_ws.get(x.device)
+    need = (B * ((H * W_ + 31) // 32) * Cc + B * groups) * 2 * 4
+    if ws is None or ws.numel() * 4 < need:
+        if ws is not None:
+            _gn_ws_retired.append(ws)
+        ws = torch.empty(max(need // 4, 1 << 18), dtype=torch.float32, device=x.device)
+        _gn_ws[x.device] = ws
+    _check(_lib.load().fluxhip_groupnorm_silu_x3(_p(x[0]), x.stride(0), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")),
+                                                 _p(out[0]), out.stride(0), B, H * W_, Cc, groups, eps, int(silu), _p(ws),
+                                                 ws.numel() * 4, _stream()), "fluxhip_groupnorm_silu_x3")
+    return out
+
+
+def softmax_rows_x3(s: torch.Tensor, scale: float, out: torch.Tensor, cols: Optional[int] = None) -> torch.Tensor:
+    """float32 logits [rows, ld] -> split probabilities out [2, rows, ld] (columns >= cols untouched)."""
+    _f32c(s, "s"); _split_ok(out, "out")
+    ld = s.shape[-1]
+    cols = ld if cols is None else cols
+    _check(_lib.load().fluxhip_softmax_rows_x3(_p(s), _p(out[0]), out.stride(0), s.numel() // ld, cols, ld, float(scale),
+                                               _stream()), "fluxhip_softmax_rows_x3")
+    return out
+
+
+def conv2d_out_image_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], clip01: bool) -> torch.Tensor:
+    """Final decoder conv (Cout <= 4) of a split tensor with float32 weights -> float32 NHWC image."""
+    _split_ok(x, "x"); _f32c(w, "w")
+    _, B, H, W_, Cin = x.shape
+    Cout = w.shape[0]
+    out = torch.empty(B, H, W_, Cout, dtype=F32, device=x.device)
+    _check(_lib.load().fluxhip_conv2d_small_x3(_p(x[0]), x.stride(0), _p(w), _p(_f32c(b, "bias")), _p(out), B, H, W_, Cin,
+                                               Cout, int(clip01), _stream()), "fluxhip_conv2d_small_x3")
+    return out
+
+
+def unpack_latents_x3(x: torch.Tensor, h: int, w: int, scale: float, shift: float, cpad: int) -> torch.Tensor:
+    """packed bf16 latents [B,L,4C] -> split [2,B,h,w,cpad] = unpack(x) / scale + shift in float32, zero-padded channels."""
+    _bf16c(x, "x")
+    B, c = x.shape[0], x.shape[-1] // 4
+    out = torch.empty(2, B, h, w, cpad, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_unpack_latents_x3(_p(x), _p(out[0]), out.stride(0), B, h, w, c, cpad, float(scale),
+                                                 float(shift), _stream()), "fluxhip_unpack_latents_x3")
+    return out
+
+
+def pixel_linear_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad_to: int, in_div: float) -> torch.Tensor:
+    _bf16c(x, "x"); _f32c(w, "w")
+    Cin, Cout = x.shape[-1], w.shape[0]
+    out = torch.empty(2, *x.shape[:-1], pad_to, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_pixel_linear_x3(_p(x), _p(w), _p(_f32c(b, "bias")), _p(out[0]), out.stride(0),
+                                               x.numel() // Cin, Cin, Cout, pad_to, float(in_div), _stream()),
+           "fluxhip_pixel_linear_x3")
     return out
 
 

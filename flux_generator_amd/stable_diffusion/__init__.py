@@ -128,22 +128,24 @@ class StableDiffusion:
                                         key=g, device=self.device)
         yield from self._denoising_loop(x_T, self.sampler.max_time, conditioning, num_steps, cfg_weight, key=g)
 
-    def decode(self, x_t):
-        """__init__.py:166-169: clip(vae.decode(x_t) / 2 + 0.5, 0, 1), fused into the last conv."""
+    def decode(self, x_t, precision: Optional[str] = None):
+        """__init__.py:166-169: clip(vae.decode(x_t) / 2 + 0.5, 0, 1), fused into the last conv.  float32 arithmetic
+        like the reference's VAE (load_autoencoder(model, False), __init__.py:25) unless precision="bf16"."""
+        precision = precision or self.autoencoder.precision
         if not self.use_graph:
-            return self.autoencoder.decode_image(x_t)
-        key = ("decode", tuple(x_t.shape))
+            return self.autoencoder.decode_image(x_t, precision)
+        key = ("decode", tuple(x_t.shape), precision)
         ent = self._graphs.get(key)
         if ent is None:
             sx = x_t.to(self.dtype).contiguous().clone()
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self.autoencoder.decode_image(sx)
+                self.autoencoder.decode_image(sx, precision)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self.autoencoder.decode_image(sx)
+                out = self.autoencoder.decode_image(sx, precision)
             ent = (g, sx, out)
             self._graphs[key] = ent
         g, sx, out = ent

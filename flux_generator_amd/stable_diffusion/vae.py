@@ -1,16 +1,17 @@
 """SD / SDXL VAE decoder on MI355X (mirror of the reference's stable_diffusion/stable_diffusion/vae.py
 decode path: Autoencoder.decode :256-258, Decoder.__call__ :209-223, Attention :25-42).
 Encoder / quant_proj (image2image) are out of the hot-path scope.  Parameter names = MLX module tree
-(what model_io.map_vae_weights produces).  bf16 storage / fp32 accumulate (reference: fp32)."""
+(what model_io.map_vae_weights produces).  Default arithmetic: the reference's float32, on the fp32-faithful
+split-bf16 kernels (vae_common.py); bf16 storage is an opt-in."""
 from __future__ import annotations
 
-import math
-from typing import Dict, Tuple, Union
+from typing import Dict, Optional, Tuple, Union
 
 import torch
 
 from .. import _lib, ops
-from ..ops import EPI_BIAS, EPI_GATE_RES, FluxHipError, make_gemm_desc
+from .. import vae_common as V
+from ..ops import FluxHipError
 from .config import AutoencoderConfig
 
 BF16 = torch.bfloat16
@@ -53,123 +54,75 @@ def vae_decoder_weight_shapes(cfg: AutoencoderConfig) -> Dict[str, Tuple[int, ..
 
 
 class Autoencoder:
-    def __init__(self, config: AutoencoderConfig, device: Union[str, torch.device] = "cuda"):
+    """precision = "fp32" (default): the reference builds this model with float16=False
+    (stable_diffusion/__init__.py:25), i.e. decodes in float32 — here the fp32-faithful split-bf16 kernels;
+    "bf16" is the bf16-storage opt-in (see vae_common.py)."""
+
+    def __init__(self, config: AutoencoderConfig, device: Union[str, torch.device] = "cuda", precision: str = "fp32"):
+        V.check_precision(precision)
         self.config = config
         self.latent_channels = config.latent_channels_in
         self.scaling_factor = config.scaling_factor
+        self.precision = precision
         if torch.device(device).type != "cuda":
             raise FluxHipError("Autoencoder needs a HIP device: there is no CPU fallback for the decode path")
         self.device = _lib.bind_device(device)
         _lib.load()
-        self._params = {k: torch.empty(*shp, dtype=BF16, device=self.device)
-                        for k, shp in vae_decoder_weight_shapes(config).items()}
-        self._conv_in_w = None
+        self._store = V.ParamStore(vae_decoder_weight_shapes(config), self.device, pad64=("decoder.conv_in.weight",))
 
     def parameters(self):
-        return self._params
+        """float32 master parameters."""
+        return self._store.master
 
     def init_random(self, seed: int = 0) -> "Autoencoder":
-        g = torch.Generator(device=self.device).manual_seed(seed)
-        for name, t in self._params.items():
-            base = name.rsplit(".", 1)[0]
-            wt = self._params[f"{base}.weight"]
-            if wt.dim() == 1:
-                t.fill_(1.0 if name.endswith(".weight") else 0.0)
-                continue
-            k = 1.0 / math.sqrt(wt[0].numel())
-            t.copy_(((torch.rand(t.shape, generator=g, device=self.device) * 2 - 1) * k).to(BF16))
-        return self.finalize()
+        self._store.init_random(seed)
+        return self
 
     def load_weights(self, weights, strict: bool = True) -> "Autoencoder":
-        items = weights.items() if isinstance(weights, dict) else weights
-        seen = set()
-        for k, w in items:
-            if k not in self._params:
-                if k.startswith("encoder.") or k.startswith("quant_proj") or not strict:
-                    continue
-                raise ValueError(f"Unexpected parameter {k}")
-            dst = self._params[k]
-            if tuple(dst.shape) != tuple(w.shape):
-                raise ValueError(f"Shape mismatch for {k}: expected {tuple(dst.shape)}, got {tuple(w.shape)}")
-            dst.copy_(w.to(device=self.device, dtype=BF16))
-            seen.add(k)
-        if strict and set(self._params) - seen:
-            raise ValueError(f"Missing parameters: {sorted(set(self._params) - seen)[:5]} ...")
-        return self.finalize()
-
-    def finalize(self) -> "Autoencoder":
-        w = self._params["decoder.conv_in.weight"]        # input channels zero-padded to 64: MFMA implicit-GEMM path
-        cin = w.shape[-1]
-        wp = torch.zeros(*w.shape[:-1], (cin + 63) // 64 * 64, dtype=BF16, device=self.device)
-        wp[..., :cin] = w
-        self._conv_in_w = wp
+        self._store.load(weights, strict, skip_prefixes=("encoder.", "quant_proj"))    # image2image only
         return self
 
     # ------------------------------------------------------------------ blocks
-    def _resnet(self, p: str, x: torch.Tensor) -> torch.Tensor:
+    def _resnet(self, p: str, x: torch.Tensor, fp32: bool = False) -> torch.Tensor:
         """ResnetBlock2D without time embedding (unet.py:152-170 as used by vae.py:56-63)."""
-        W, G = self._params, self.config.norm_num_groups
-        h = ops.groupnorm_silu(x, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], G, 1e-5, True)
-        h = ops.conv2d(h, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"])
-        h = ops.groupnorm_silu(h, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], G, 1e-5, True)
-        if f"{p}.conv_shortcut.weight" in W:
-            x = ops.conv2d(x, W[f"{p}.conv_shortcut.weight"], W[f"{p}.conv_shortcut.bias"])
-        return ops.conv2d(h, W[f"{p}.conv2.weight"], W[f"{p}.conv2.bias"], res=x)
+        return V.resnet(self._store, fp32, p, x, "conv_shortcut", self.config.norm_num_groups, 1e-5)
 
-    def _attention(self, p: str, x: torch.Tensor) -> torch.Tensor:
+    def _attention(self, p: str, x: torch.Tensor, fp32: bool = False) -> torch.Tensor:
         """Attention.__call__ (vae.py:25-42): single head, softmax((q/sqrt(C)) k^T) v, fp32 logits."""
-        W = self._params
-        B, H, Wd, C = x.shape
-        N = H * Wd
-        Np = (N + 63) // 64 * 64
-        y = ops.groupnorm_silu(x, W[f"{p}.group_norm.weight"], W[f"{p}.group_norm.bias"], self.config.norm_num_groups,
-                               1e-5, False)
-        q = ops.linear(y.view(B, N, C), W[f"{p}.query_proj.weight"], W[f"{p}.query_proj.bias"])
-        k = ops.linear(y.view(B, N, C), W[f"{p}.key_proj.weight"], W[f"{p}.key_proj.bias"])
-        out = torch.empty_like(x)
-        vt = torch.zeros(C, Np, dtype=BF16, device=x.device)
-        s = torch.empty(N, Np, dtype=torch.float32, device=x.device)
-        pm = torch.zeros(N, Np, dtype=BF16, device=x.device)
-        o = torch.empty(N, C, dtype=BF16, device=x.device)
-        for b in range(B):
-            yb = y[b].view(N, C)
-            ops.gemm(make_gemm_desc([dict(A=W[f"{p}.value_proj.weight"].data_ptr(), W=yb.data_ptr(),
-                                          bias=W[f"{p}.value_proj.bias"].data_ptr(), C=vt.data_ptr(), M=C)],
-                                    1, N, C, C, Np, EPI_BIAS, row_bias=True))
-            ops.gemm(make_gemm_desc([dict(A=q[b].data_ptr(), W=k[b].data_ptr(), C=s.data_ptr(), M=N)], 1, N, C, C, Np,
-                                    EPI_BIAS, out_f32=True))
-            ops.softmax_rows(s, C ** -0.5, out=pm, cols=N)
-            ops.gemm(make_gemm_desc([dict(A=pm.data_ptr(), W=vt.data_ptr(), C=o.data_ptr(), M=N)], 1, C, Np, Np, C))
-            ops.linear(o, W[f"{p}.out_proj.weight"], W[f"{p}.out_proj.bias"], epi=EPI_GATE_RES,
-                       out=out[b].view(N, C), res=x[b].view(N, C))
-        return out
+        return V.attention(self._store, fp32, p, x, "group_norm", "query_proj", "key_proj", "value_proj", "out_proj",
+                           self.config.norm_num_groups, 1e-5)
 
-    def _decode(self, z: torch.Tensor, clip01: bool) -> torch.Tensor:
-        cfg, W = self.config, self._params
+    def _decode(self, z: torch.Tensor, clip01: bool, precision: Optional[str] = None) -> torch.Tensor:
+        V.check_precision(precision)
+        fp32 = (precision or self.precision) == "fp32"
+        cfg, S = self.config, self._store
         z = z.to(BF16).contiguous()
         cin = cfg.latent_channels_in
+        cpad = (cin + 63) // 64 * 64
         # z / scaling_factor -> post_quant_proj (vae.py:256-258), output zero-padded to 64 channels
-        x = ops.pixel_linear(z, W["post_quant_proj.weight"], W["post_quant_proj.bias"], (cin + 63) // 64 * 64,
-                             self.scaling_factor)
-        x = ops.conv2d(x, self._conv_in_w, W["decoder.conv_in.bias"])
-        x = self._resnet("decoder.mid_blocks.0", x)
-        x = self._attention("decoder.mid_blocks.1", x)
-        x = self._resnet("decoder.mid_blocks.2", x)
+        if fp32:
+            x = ops.pixel_linear_x3(z, S.get("post_quant_proj.weight", "f32"), S.get("post_quant_proj.bias", "f32"), cpad,
+                                    self.scaling_factor)
+        else:
+            x = ops.pixel_linear(z, S.get("post_quant_proj.weight", "bf16"), S.get("post_quant_proj.bias", "bf16"), cpad,
+                                 self.scaling_factor)
+        x = V.conv(S, fp32, "decoder.conv_in", x)
+        x = self._resnet("decoder.mid_blocks.0", x, fp32)
+        x = self._attention("decoder.mid_blocks.1", x, fp32)
+        x = self._resnet("decoder.mid_blocks.2", x, fp32)
         n = len(cfg.block_out_channels)
         for i in range(n):
             for j in range(cfg.layers_per_block + 1):
-                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x)
+                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, fp32)
             if i < n - 1:
-                x = ops.conv2d(x, W[f"decoder.up_blocks.{i}.upsample.weight"], W[f"decoder.up_blocks.{i}.upsample.bias"],
-                               ups=True)
-        x = ops.groupnorm_silu(x, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"],
-                               cfg.norm_num_groups, 1e-5, True)
-        return ops.conv2d_out_image(x, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], clip01)
+                x = V.conv(S, fp32, f"decoder.up_blocks.{i}.upsample", x, ups=True)
+        return V.norm_out_conv_out(S, fp32, "decoder.conv_norm_out", "decoder.conv_out", x, cfg.norm_num_groups, 1e-5,
+                                   clip01)
 
-    def decode(self, z: torch.Tensor) -> torch.Tensor:
+    def decode(self, z: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
         """Autoencoder.decode (vae.py:256-258): [B,h,w,4] -> [B,8h,8w,3] float32 (unclipped)."""
-        return self._decode(z, clip01=False)
+        return self._decode(z, False, precision)
 
-    def decode_image(self, z: torch.Tensor) -> torch.Tensor:
+    def decode_image(self, z: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
         """StableDiffusion.decode fused (__init__.py:166-169): clip(decode(z)/2 + 0.5, 0, 1)."""
-        return self._decode(z, clip01=True)
+        return self._decode(z, True, precision)

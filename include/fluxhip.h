@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define FLUXHIP_ABI_VERSION 1
+#define FLUXHIP_ABI_VERSION 2
 
 int fluxhip_abi_version(void);
 /* "gfx950" — the only architecture this library is built for. */
@@ -214,6 +214,61 @@ int fluxhip_pixel_linear_bf16(const void* x, const void* w, const void* bias, vo
 /* nn.SinusoidalPositionalEncoding(cos_first=True): out[n] = [cos(x[n]*sig) | sin(x[n]*sig)], x and
  * sig float32, out bf16 [n][2*half] (unet.py:283-292,301-313,413,419). */
 int fluxhip_sincos_embed_f32(const void* x, const void* sig, void* out, int n, int half, void* stream);
+
+/* ---- fp32-faithful ("bf16x3") VAE decode path -------------------------------------------------
+ * The reference decodes both VAEs in float32: flux/utils.py:137-143 loads ae.safetensors in the checkpoint
+ * dtype and never casts (bf16 latents x fp32 weights promote to fp32), and
+ * stable_diffusion/stable_diffusion/__init__.py:25 calls load_autoencoder(model, False).  gfx950's fp32 MFMA
+ * runs at 1/16 of the bf16 rate, so this path keeps every fp32 value x as TWO bf16 planes
+ *     hi = bf16(x),  lo = bf16(x - hi)        (x = hi + lo up to 2^-17 |x|)
+ * and evaluates a product as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16 matrix cores with fp32
+ * accumulation (three MFMA passes; the dropped lo*lo term is 2^-16 relative).  Norm statistics, softmax and
+ * the final 128->3 conv are plain fp32 arithmetic on hi + lo.  In every entry point below a "split tensor"
+ * is the hi-plane pointer plus the ELEMENT offset of its lo plane (`*_lo`); biases / norm affines are float32. */
+
+/* x float32 [n] -> hi / lo bf16 planes (weights at load time, test inputs), and back (hi + lo). */
+int fluxhip_split_f32(const void* x, void* hi, void* lo, int64_t n, void* stream);
+int fluxhip_join_f32(const void* hi, const void* lo, void* out, int64_t n, void* stream);
+
+typedef struct fluxhip_gemm_x3_desc {
+  const void* A;         /* split [nbatch][M][lda]                                        */
+  const void* W;         /* split [N][K]                                                  */
+  const void* bias;      /* float32 [N] (or [M] with row_bias) or NULL                    */
+  void* C;               /* split [nbatch][M][ldc], or float32 when out_f32               */
+  const void* res;       /* split residual indexed like C (EPI_GATE_RES, gate = 1)        */
+  int64_t a_lo, w_lo, c_lo, res_lo;   /* element offsets of the lo planes (a_lo, w_lo % 8 == 0; c_lo, res_lo % 4 == 0) */
+  int64_t a_bstride, c_bstride, w_bstride;
+  int32_t M, nbatch, N, K, lda, ldc;
+  int32_t epi;           /* FLUXHIP_EPI_BIAS or FLUXHIP_EPI_GATE_RES                      */
+  int32_t row_bias, out_f32, tile_cfg;
+  float alpha;
+  int32_t _pad;
+} fluxhip_gemm_x3_desc;
+/* nn.Linear in float32 (AttnBlock q/k/v/proj_out, flux/autoencoder.py:36-39; the QK^T and PV products of its
+ * single-head attention, :49; vae.py:25-42). */
+int fluxhip_gemm_x3(const fluxhip_gemm_x3_desc* d, void* stream);
+/* nn.Conv2d in float32 (same geometry rules as fluxhip_conv2d_bf16; res != NULL adds the split residual). */
+int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int64_t w_lo, const void* bias,
+                      const void* res, int64_t res_lo, void* out, int64_t out_lo, int B, int Hs, int Ws,
+                      int Cin, int Cout, int ksize, int stride, int pad, int ups, const void* zero16,
+                      void* stream);
+/* GroupNorm [+ SiLU] on a split NHWC tensor with float32 gamma / beta; float32 arithmetic throughout. */
+int fluxhip_groupnorm_silu_x3(const void* x, int64_t x_lo, const void* gamma, const void* beta, void* out,
+                              int64_t out_lo, int B, int HW, int C, int G, float eps, int silu, void* ws,
+                              int64_t ws_bytes, void* stream);
+/* softmax(scale * S) of float32 logits -> split P. */
+int fluxhip_softmax_rows_x3(const void* s, void* p, int64_t p_lo, int64_t rows, int cols, int ld, float scale,
+                            void* stream);
+/* Final 3x3 conv to <= 4 channels (Cin in {64,128,256,512}) of a split tensor with float32 weights
+ * [Cout][3][3][Cin] and bias -> float32 image, optional clip((y+1),0,2)*0.5 (flux/flux.py:162). */
+int fluxhip_conv2d_small_x3(const void* x, int64_t x_lo, const void* w, const void* bias, void* out, int B,
+                            int H, int W, int Cin, int Cout, int clip01, void* stream);
+/* fluxhip_unpack_latents_bf16 producing a split tensor zero-padded to Cpad channels (conv_in's K-step). */
+int fluxhip_unpack_latents_x3(const void* x, void* out, int64_t out_lo, int B, int h, int w, int C, int Cpad,
+                              float scale, float shift, void* stream);
+/* fluxhip_pixel_linear_bf16 with float32 weights / bias producing a split tensor (SD VAE post_quant_proj). */
+int fluxhip_pixel_linear_x3(const void* x, const void* w, const void* bias, void* out, int64_t out_lo,
+                            int64_t npix, int Cin, int Cout, int Cpad, float in_div, void* stream);
 
 /* ---- text encoders (flux/t5.py, flux/clip.py) ------------------------- */
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_loader_checks_abi_and_arch():
     from flux_generator_amd import _lib
     lib = _lib.load()
-    assert lib.fluxhip_abi_version() == 1 and lib.fluxhip_arch() == b"gfx950"
+    assert lib.fluxhip_abi_version() == 2 and lib.fluxhip_arch() == b"gfx950"
 
 
 def test_gemm_desc_layout_matches_header():
@@ -35,6 +35,9 @@ def test_gemm_desc_layout_matches_header():
     from flux_generator_amd._lib import GemmDesc, GemmGroup
     assert ctypes.sizeof(GemmGroup) == 88 and GemmGroup.M.offset == 80
     assert ctypes.sizeof(GemmDesc) == 248 and GemmDesc.C2.offset == 216 and GemmDesc.alpha.offset == 240
+    from flux_generator_amd._lib import GemmX3Desc      # fluxhip_gemm_x3_desc: 5 pointers, 7 int64, 10 int32, float, pad
+    assert ctypes.sizeof(GemmX3Desc) == 144 and GemmX3Desc.a_lo.offset == 40 and GemmX3Desc.M.offset == 96
+    assert GemmX3Desc.alpha.offset == 136
 
 
 def test_tile_picker_is_host_only():

@@ -149,18 +149,27 @@ def test_sd_denoising_step_cfg_and_samplers(dev):
 
 
 def test_sd_vae_decode_tiny(dev):
+    """SD VAE decoder: default = the reference's float32 arithmetic (load_autoencoder(model, False),
+    stable_diffusion/__init__.py:25) on the fp32-faithful split-bf16 kernels, image error <= 1/255 vs the fp32 oracle
+    on true float32 weights; the bf16-storage opt-in keeps its 0.03 bound."""
     from flux_generator_amd.stable_diffusion.config import AutoencoderConfig
     from flux_generator_amd.stable_diffusion.vae import Autoencoder
     kw = dict(block_out_channels=(128, 256), layers_per_block=1, scaling_factor=0.13025)
     ocfg = S.AutoencoderConfig(**kw)
-    W = {k: v.to(BF).float() for k, v in O.init_weights(S.vae_decoder_weight_shapes(ocfg), seed=4, norm_jitter=0.2).items()}
+    W = O.init_weights(S.vae_decoder_weight_shapes(ocfg), seed=4, norm_jitter=0.2)
     ae = Autoencoder(AutoencoderConfig(**kw), device=dev).load_weights(W)
+    assert ae.precision == "fp32"
     z = torch.randn(2, 8, 8, 4, generator=torch.Generator().manual_seed(1)).to(BF)
     got = ae.decode_image(z.to(dev))
     ref = S.sd_decode(ocfg, W, z.float())
     assert got.shape == ref.shape == (2, 16, 16, 3)
-    assert float((got.cpu() - ref).abs().max()) < 0.03 and rel_l2(got, ref) < 2e-2
-    assert rel_l2(ae.decode(z.to(dev)), S.vae_decode(ocfg, W, z.float())) < 2e-2
+    d = float((got.cpu() - ref).abs().max())
+    print(f"sd vae tiny: fp32-faithful max-abs {d:.2e}")
+    assert d <= 1.0 / 255 and rel_l2(got, ref) < 1e-3
+    assert rel_l2(ae.decode(z.to(dev)), S.vae_decode(ocfg, W, z.float())) < 1e-3
+    g16 = ae.decode_image(z.to(dev), precision="bf16")
+    assert float((g16.cpu() - ref).abs().max()) < 0.03 and rel_l2(g16, ref) < 2e-2
+    assert rel_l2(ae.decode(z.to(dev), precision="bf16"), S.vae_decode(ocfg, W, z.float())) < 2e-2
 
 
 def test_sdxl_pipeline_surface(dev):
