@@ -32,6 +32,7 @@ enum GemmEpi : int {
   EPI_SILU = 4,       // C = silu(acc + bias)
   EPI_GEGLU = 5,      // C = res * gelu_erf(acc + bias)       (UNet GEGLU: linear1(y) * gelu(linear2(y)))
   EPI_QUICK_GELU = 6, // C = v * sigmoid(1.702 v), v = acc + bias   (CLIP "quick_gelu", flux/clip.py:9)
+  EPI_GELU_ERF = 7,   // C = gelu_erf(acc + bias)   (nn.gelu: OpenCLIP text towers of SD 2.1 / SDXL, stable_diffusion/.../clip.py:11)
 };
 
 struct GemmGroup {
@@ -881,6 +882,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       for (int r = 0; r < NV; ++r) v[r] = silu_f(v[r]);
     } else if (epi == EPI_QUICK_GELU) {
       for (int r = 0; r < NV; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+    } else if (epi == EPI_GELU_ERF) {
+      for (int r = 0; r < NV; ++r) v[r] = gelu_erf_f(v[r]);
     } else if (epi == EPI_GATE_RES) {
       const uint32_t* rp = (const uint32_t*)(gRes + (long long)b * c_bs + (long long)m * p.ldc + n);
       if (gGate) {

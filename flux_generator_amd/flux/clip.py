@@ -1,5 +1,6 @@
 """CLIP text model on MI355X — host-side mirror of the reference's flux/clip.py (CLIPTextModelConfig,
-CLIPOutput, CLIPTextModel.sanitize/__call__).  LayerNorm kernel -> fused [q;k] GEMM (+bias) + V^T GEMM
+CLIPOutput, CLIPTextModel.sanitize/__call__) and of stable_diffusion/stable_diffusion/clip.py (the same
+transformer with an optional bias-free text_projection on the pooled row and exact-erf "gelu" towers).  LayerNorm kernel -> fused [q;k] GEMM (+bias) + V^T GEMM
 (row bias) -> causal head_dim-64 flash attention -> out_proj + residual epilogue -> LayerNorm ->
 linear1 with the quick_gelu epilogue -> linear2 + residual; pooled output = row at argmax(token id)."""
 from __future__ import annotations
@@ -11,7 +12,9 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from .. import _lib, ops
-from ..ops import EPI_GATE_RES, EPI_QUICK_GELU, FluxHipError, make_gemm_desc
+from ..ops import EPI_GATE_RES, EPI_GELU_ERF, EPI_QUICK_GELU, FluxHipError, make_gemm_desc
+
+_ACT_EPI = {"quick_gelu": EPI_QUICK_GELU, "gelu": EPI_GELU_ERF}     # stable_diffusion/.../clip.py:11
 
 BF16 = torch.bfloat16
 
@@ -25,12 +28,17 @@ class CLIPTextModelConfig:
     max_length: int = 77
     vocab_size: int = 49408
     hidden_act: str = "quick_gelu"
+    projection_dim: Optional[int] = None     # stable_diffusion/.../config.py: text_projection of "...WithProjection" towers
 
     @classmethod
     def from_dict(cls, config):
+        """HF config.json -> config.  The projection exists only for CLIPTextModelWithProjection checkpoints
+        (stable_diffusion/.../model_io.py:246-257)."""
+        with_projection = "WithProjection" in (config.get("architectures") or [""])[0]
         return cls(num_layers=config["num_hidden_layers"], model_dims=config["hidden_size"],
                    num_heads=config["num_attention_heads"], max_length=config["max_position_embeddings"],
-                   vocab_size=config["vocab_size"], hidden_act=config["hidden_act"])
+                   vocab_size=config["vocab_size"], hidden_act=config.get("hidden_act", "quick_gelu"),
+                   projection_dim=config["projection_dim"] if with_projection else None)
 
 
 # openai/clip-vit-large-patch14 text tower as shipped in FLUX.1 text_encoder/config.json
@@ -48,8 +56,8 @@ class CLIPTextModel:
     def __init__(self, config: CLIPTextModelConfig, device: Union[str, torch.device] = "cuda"):
         if config.model_dims // config.num_heads != 64:
             raise ValueError("libfluxhip CLIP attention is built for head_dim 64")
-        if config.hidden_act != "quick_gelu":
-            raise ValueError("only quick_gelu (the FLUX.1 CLIP-L text tower) is built")
+        if config.hidden_act not in _ACT_EPI:
+            raise ValueError(f"hidden_act must be one of {sorted(_ACT_EPI)}")
         self.config = config
         if torch.device(device).type != "cuda":
             raise FluxHipError("CLIPTextModel needs a HIP device")
@@ -66,6 +74,8 @@ class CLIPTextModel:
                 shp[f"{p}.attention.{n}.weight"] = (D, D); shp[f"{p}.attention.{n}.bias"] = (D,)
             shp[f"{p}.linear1.weight"] = (4 * D, D); shp[f"{p}.linear1.bias"] = (4 * D,)
             shp[f"{p}.linear2.weight"] = (D, 4 * D); shp[f"{p}.linear2.bias"] = (D,)
+        if config.projection_dim is not None:
+            shp["text_projection.weight"] = (config.projection_dim, D)
         self._params = {k: torch.empty(*v, dtype=BF16, device=self.device) for k, v in shp.items()}
         self._qk: Dict[int, tuple] = {}
 
@@ -152,10 +162,13 @@ class CLIPTextModel:
             ops.attention_masked(qk, qk[..., D:], vt, o, B, H, N, N, Tpad, st, st, D, 64 ** -0.5, causal=True)
             h = ops.linear(o, P[f"{p}.attention.out_proj.weight"], P[f"{p}.attention.out_proj.bias"], epi=EPI_GATE_RES, res=h)
             y = ops.layernorm_affine(h, P[f"{p}.layer_norm2.weight"], P[f"{p}.layer_norm2.bias"])
-            y = ops.linear(y, P[f"{p}.linear1.weight"], P[f"{p}.linear1.bias"], epi=EPI_QUICK_GELU)
+            y = ops.linear(y, P[f"{p}.linear1.weight"], P[f"{p}.linear1.bias"], epi=_ACT_EPI[c.hidden_act])
             h = ops.linear(y, P[f"{p}.linear2.weight"], P[f"{p}.linear2.bias"], epi=EPI_GATE_RES, res=h)
             hs.append(h)
         last = ops.layernorm_affine(h, P["final_layer_norm.weight"], P["final_layer_norm.bias"])
         rows = (torch.arange(B, dtype=torch.int32) * N + eos.cpu().to(torch.int32)).to(self.device).contiguous()
         pooled = ops.embedding(rows, last.view(B * N, D))
+        if c.projection_dim is not None:        # text_projection (no bias), stable_diffusion/.../clip.py:107-108
+            pooled = torch.cat([ops.small_linear(pooled[i:i + 16].contiguous(), P["text_projection.weight"], None)
+                                for i in range(0, B, 16)], dim=0)
         return CLIPOutput(pooled_output=pooled, last_hidden_state=last, hidden_states=hs)

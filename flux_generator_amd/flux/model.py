@@ -186,6 +186,35 @@ class Flux:
                 raise ValueError(f"Missing parameters: {sorted(missing)[:5]} ...")
         return self
 
+    def fuse_lora(self, adapter: Dict[str, torch.Tensor], scale: float = 1.0) -> int:
+        """LoRA adapters at inference (flux/lora.py:28-43, flux/flux.py:229-246): for every Linear `name` with
+        `name.lora_a` [in, r] and `name.lora_b` [r, out] in `adapter`,  W <- W + (scale * lora_b^T @ lora_a^T).astype(bf16).
+        One libfluxhip GEMM per layer — M = out, N = in, K = r zero-padded to the 64-wide K-step, alpha = scale,
+        residual epilogue in place on the weight (the epilogue rounds the product to bf16 before the add, exactly the
+        reference's two roundings).  Returns the number of fused layers."""
+        names = sorted(k[: -len(".lora_a")] for k in adapter if k.endswith(".lora_a"))
+        for n in names:
+            if f"{n}.lora_b" not in adapter:
+                raise ValueError(f"adapter has {n}.lora_a but no {n}.lora_b")
+            if f"{n}.weight" not in self._params:
+                raise ValueError(f"adapter targets unknown layer {n}")
+        for n in names:
+            W = self._params[f"{n}.weight"]                   # [out, in] (modulation layers: a view into the table)
+            a, b = adapter[f"{n}.lora_a"], adapter[f"{n}.lora_b"]
+            out_d, in_d = W.shape
+            r = a.shape[1]
+            if tuple(a.shape) != (in_d, r) or tuple(b.shape) != (r, out_d):
+                raise ValueError(f"Shape mismatch for {n}: lora_a {tuple(a.shape)}, lora_b {tuple(b.shape)}, weight {tuple(W.shape)}")
+            rp = (r + 63) // 64 * 64
+            bt = torch.zeros(out_d, rp, dtype=BF16, device=self.device)     # lora_b^T, K-contiguous
+            bt[:, :r] = b.to(device=self.device, dtype=BF16).t()
+            ap = torch.zeros(in_d, rp, dtype=BF16, device=self.device)      # lora_a is already [in, r] = the "weight" operand
+            ap[:, :r] = a.to(device=self.device, dtype=BF16)
+            ops.gemm(make_gemm_desc([dict(A=bt.data_ptr(), W=ap.data_ptr(), C=W.data_ptr(), res=W.data_ptr(), M=out_d)],
+                                    1, in_d, rp, rp, in_d, EPI_GATE_RES, alpha=float(scale)))
+        torch.cuda.synchronize(self.device)
+        return len(names)
+
     # ------------------------------------------------------------------ workspace + launch plan
     def _workspace(self, B: int, S: int, L: int) -> dict:
         key = (B, S, L)

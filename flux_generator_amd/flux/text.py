@@ -1,11 +1,9 @@
-"""Stand-ins for the text side of the pipeline (tokenizers, T5-XXL, CLIP-L).
+"""Offline stand-in for the tokenizers' vocabulary files.
 
-The text encoders sit immediately BEFORE the denoise hot path and are the first "next" row of the
-scope table; their checkpoints and vocabularies are not available offline.  These
-classes only produce conditioning tensors with the reference's shapes and dtypes
-(txt [B,S,4096] bf16, pooled vec [B,768] bf16; flux/flux.py:73-85) deterministically from the
-prompt, so the pipeline surface can be driven end to end.  They are NOT the reference's encoders.
-"""
+The real tokenizers (flux/tokenizers.py: CLIP BPE, T5 SentencePiece) need vocab.json / merges.txt / spiece.model,
+which are not available without the hub.  When those files are not configured the loaders substitute this
+deterministic hash tokenizer AND SAY SO (a warning): it keeps the reference's padding contract so the pipelines can be
+driven end to end with random-init weights, but its token ids are not the models' ids."""
 from __future__ import annotations
 
 import hashlib
@@ -38,31 +36,3 @@ class HashTokenizer:
             n, fill = (self.max_length if pad else max(len(r) for r in rows)), 0
         n = (n + 3) // 4 * 4 if not self.pad_with_eos else n
         return torch.tensor([r + [fill] * (n - len(r)) for r in rows], dtype=torch.int32)
-
-
-class _SyntheticEncoder:
-    def __init__(self, dim: int, device, table: int = 4096, seed: int = 7, scale: float = 0.1):
-        g = torch.Generator(device="cpu").manual_seed(seed)
-        self.table = (torch.randn(table, dim, generator=g) * scale).to(torch.bfloat16).to(device)
-        self.device = torch.device(device)
-
-    def _embed(self, tokens: torch.Tensor) -> torch.Tensor:
-        return self.table[(tokens.to(self.device).long() % self.table.shape[0])]
-
-
-class SyntheticT5(_SyntheticEncoder):
-    def __call__(self, tokens: torch.Tensor) -> torch.Tensor:   # [B,S] -> [B,S,dim]
-        return self._embed(tokens)
-
-
-class _Pooled:
-    def __init__(self, pooled):
-        self.pooled_output = pooled
-
-
-class SyntheticCLIP(_SyntheticEncoder):
-    def __init__(self, dim: int, device):
-        super().__init__(dim, device, seed=11, scale=1.0)
-
-    def __call__(self, tokens: torch.Tensor) -> _Pooled:          # [B,77] -> .pooled_output [B,dim]
-        return _Pooled(self._embed(tokens).float().mean(dim=1).to(torch.bfloat16))

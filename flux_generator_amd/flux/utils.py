@@ -135,6 +135,8 @@ def load_clip_tokenizer(name: str):
             merges = f.read().strip().split("\n")[1: 49152 - 256 - 2 + 1]
         ranks = {tuple(m.split()): i for i, m in enumerate(merges)}
         return CLIPTokenizer(ranks, vocab, max_length=77)
+    warnings.warn("CLIP tokenizer: no tokenizer/vocab.json under FLUX_TEXT_DIR; substituting a deterministic hash "
+                  "tokenizer (token ids are NOT CLIP's)")
     return HashTokenizer(max_length=77, vocab=49408, pad_with_eos=True)
 
 
@@ -145,4 +147,6 @@ def load_t5_tokenizer(name: str, pad: bool = True):
     n = 256 if "schnell" in name else 512
     if mf and os.path.exists(mf):
         return T5Tokenizer(mf, n)
+    warnings.warn("T5 tokenizer: no tokenizer_2/spiece.model under FLUX_TEXT_DIR; substituting a deterministic hash "
+                  "tokenizer (token ids are NOT T5's)")
     return HashTokenizer(max_length=n, vocab=32128)

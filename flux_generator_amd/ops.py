@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import GemmDesc, GemmX3Desc
 
-EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU, EPI_QUICK_GELU = 0, 1, 2, 3, 4, 5, 6
+EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU, EPI_QUICK_GELU, EPI_GELU_ERF = 0, 1, 2, 3, 4, 5, 6, 7
 BF16 = torch.bfloat16
 
 

@@ -14,7 +14,9 @@ from typing import Optional
 
 import torch
 
-from ..flux.text import HashTokenizer, _SyntheticEncoder
+from ..flux.text import HashTokenizer
+from ..flux.tokenizers import CLIPTokenizer
+from .clip import CLIPTextModel, CLIPTextModelConfig, map_clip_text_encoder_weights
 from .config import AutoencoderConfig, DiffusionConfig, UNetConfig
 from .unet import UNetModel
 from .vae import Autoencoder
@@ -159,35 +161,64 @@ def load_diffusion_config(key: str = _DEFAULT_MODEL) -> DiffusionConfig:
     return DiffusionConfig(beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012, num_train_steps=1000)
 
 
-# --- text side: stand-ins (the CLIP text encoders are a "next" row) ---------------
-class _CLIPOut:
-    def __init__(self, h, pooled):
-        self.last_hidden_state = h
-        self.hidden_states = [h, h]
-        self.pooled_output = pooled
+# --- text side (stable_diffusion/.../model_io.py:229-265,313-330) -------------------------------------
+# The values of the hub's text_encoder*/config.json files, used when SD_WEIGHTS_DIR has no config.json.
+_TEXT_CONFIGS = {
+    ("stabilityai/sdxl-turbo", "text_encoder"): dict(num_layers=12, model_dims=768, num_heads=12, max_length=77,
+                                                    vocab_size=49408, hidden_act="quick_gelu", projection_dim=None),
+    ("stabilityai/sdxl-turbo", "text_encoder_2"): dict(num_layers=32, model_dims=1280, num_heads=20, max_length=77,
+                                                      vocab_size=49408, hidden_act="gelu", projection_dim=1280),
+    ("stabilityai/stable-diffusion-2-1-base", "text_encoder"): dict(num_layers=23, model_dims=1024, num_heads=16,
+                                                                    max_length=77, vocab_size=49408, hidden_act="gelu",
+                                                                    projection_dim=None),
+}
 
 
-class SyntheticCLIPText(_SyntheticEncoder):
-    def __init__(self, dim: int, device, seed: int):
-        super().__init__(dim, device, seed=seed, scale=1.0)
-
-    def __call__(self, tokens):
-        h = self._embed(tokens)
-        return _CLIPOut(h, h.float().mean(dim=1).to(torch.bfloat16))
-
-
-def load_text_encoder(key: str = _DEFAULT_MODEL, float16: bool = False, model_key: str = "text_encoder", device="cuda"):
+def load_text_encoder(key: str = _DEFAULT_MODEL, float16: bool = False, model_key: str = "text_encoder",
+                      config_key: Optional[str] = None, device="cuda", seed: int = 21) -> CLIPTextModel:
+    """The real CLIP text transformer on libfluxhip (flux/clip.py): config from <SD_WEIGHTS_DIR>/<key>/<model_key>/
+    config.json when present (else the built-in hub values), weights from .../model.safetensors through
+    map_clip_text_encoder_weights; random init (with a warning) when no checkpoint is configured."""
+    import json
     _check_key(key, "load_text_encoder")
-    dims = _MODELS[key]["text_dims"]
-    idx = 1 if model_key == "text_encoder_2" else 0
-    return SyntheticCLIPText(dims[idx], device, seed=21 + idx)
+    cfg_path = _weights_file(key, f"{model_key}/config.json")
+    if cfg_path:
+        with open(cfg_path) as f:
+            config = CLIPTextModelConfig.from_dict(json.load(f))
+    else:
+        config = CLIPTextModelConfig(**_TEXT_CONFIGS[(key, model_key)])
+    model = CLIPTextModel(config, device=device)
+    path = _weights_file(key, f"{model_key}/model.safetensors")
+    if path:
+        model.load_weights(_load_mapped(map_clip_text_encoder_weights, path))
+    else:
+        warnings.warn(f"{key}: no {model_key} weights under SD_WEIGHTS_DIR; using a random-init CLIP text transformer "
+                      "(images will not follow the prompt)")
+        model.init_random(seed + (1 if model_key.endswith("_2") else 0))
+    return model
 
 
-class _Tok(HashTokenizer):
+class _HashTok(HashTokenizer):
+    """Stand-in used only when no vocab.json / merges.txt is available offline (says so when substituted)."""
+
     def tokenize(self, text, prepend_bos=True, append_eos=True):
         return HashTokenizer.tokenize(self, text)
 
 
 def load_tokenizer(key: str = _DEFAULT_MODEL, vocab_key: str = "tokenizer_vocab", merges_key: str = "tokenizer_merges"):
+    """The CLIP BPE tokenizer from <SD_WEIGHTS_DIR>/<key>/tokenizer[_2]/{vocab.json,merges.txt}
+    (model_io.py:313-330: merges lines 1 .. 49152-256-2)."""
+    import json
     _check_key(key, "load_tokenizer")
-    return _Tok(max_length=77, vocab=49408)
+    sub = "tokenizer_2" if "tokenizer_2" in vocab_key else "tokenizer"
+    vf, mf = _weights_file(key, f"{sub}/vocab.json"), _weights_file(key, f"{sub}/merges.txt")
+    if vf and mf:
+        with open(vf, encoding="utf-8") as f:
+            vocab = json.load(f)
+        with open(mf, encoding="utf-8") as f:
+            merges = f.read().strip().split("\n")[1: 49152 - 256 - 2 + 1]
+        ranks = {tuple(m.split()): i for i, m in enumerate(merges)}
+        return CLIPTokenizer(ranks, vocab, max_length=77)
+    warnings.warn(f"{key}: no {sub}/vocab.json + merges.txt under SD_WEIGHTS_DIR; substituting a deterministic hash "
+                  "tokenizer (token ids are NOT CLIP's)")
+    return _HashTok(max_length=77, vocab=49408, pad_with_eos=True)

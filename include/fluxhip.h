@@ -33,7 +33,8 @@ enum {
   FLUXHIP_EPI_SPLIT_GELU = 3, /* cols <  n_split -> C ; cols >= n_split -> gelu_tanh -> C2     */
   FLUXHIP_EPI_SILU = 4,       /* C = silu(A W^T + b)                                            */
   FLUXHIP_EPI_GEGLU = 5,      /* C = res * gelu_erf(A W^T + b)       UNet GEGLU (unet.py:74-78) */
-  FLUXHIP_EPI_QUICK_GELU = 6  /* C = v * sigmoid(1.702 v)            CLIP quick_gelu (flux/clip.py:9) */
+  FLUXHIP_EPI_QUICK_GELU = 6, /* C = v * sigmoid(1.702 v)            CLIP quick_gelu (flux/clip.py:9) */
+  FLUXHIP_EPI_GELU_ERF = 7    /* C = gelu_erf(A W^T + b)             nn.gelu: OpenCLIP text towers (stable_diffusion/.../clip.py:11) */
 };
 
 /* One operand group of a (possibly grouped) GEMM. Two groups share N, K, the epilogue and the

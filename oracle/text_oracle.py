@@ -112,6 +112,7 @@ class CLIPTextModelConfig:
     max_length: int = 77
     vocab_size: int = 49408
     hidden_act: str = "quick_gelu"
+    projection_dim: Optional[int] = None      # stable_diffusion/stable_diffusion/clip.py:76-79 (text_projection, no bias)
 
 
 def quick_gelu(x: Tensor) -> Tensor:
@@ -150,7 +151,10 @@ def clip_text_model(cfg: CLIPTextModelConfig, W: Dict[str, Tensor], tokens: Tens
         x = y + x
         hs.append(x)
     x = F.layer_norm(x.float(), (cfg.model_dims,), W["final_layer_norm.weight"].float(), W["final_layer_norm.bias"].float(), 1e-5).to(x.dtype)
-    return CLIPOutput(pooled_output=x[torch.arange(B), eos], last_hidden_state=x, hidden_states=hs)
+    pooled = x[torch.arange(B), eos]
+    if cfg.projection_dim is not None:      # stable_diffusion/stable_diffusion/clip.py:107-108
+        pooled = linear(pooled, W["text_projection.weight"])
+    return CLIPOutput(pooled_output=pooled, last_hidden_state=x, hidden_states=hs)
 
 
 def clip_weight_shapes(cfg: CLIPTextModelConfig) -> Dict[str, Tuple[int, ...]]:
@@ -167,4 +171,6 @@ def clip_weight_shapes(cfg: CLIPTextModelConfig) -> Dict[str, Tuple[int, ...]]:
             s[f"{p}.attention.{n}.bias"] = (D,)
         s[f"{p}.linear1.weight"] = (4 * D, D); s[f"{p}.linear1.bias"] = (4 * D,)
         s[f"{p}.linear2.weight"] = (D, 4 * D); s[f"{p}.linear2.bias"] = (D,)
+    if cfg.projection_dim is not None:
+        s["text_projection.weight"] = (cfg.projection_dim, D)
     return s

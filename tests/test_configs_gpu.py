@@ -359,3 +359,61 @@ def test_sharded_pipeline_nccl_world1(dev, monkeypatch):
         assert got.float().std() > 1.0
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ LoRA adapters at inference
+def test_lora_adapter_fuse(dev, tmp_path, monkeypatch):
+    """--adapter / --fuse-adapter (txt2image.py:30-37,76-77; flux/lora.py:28-43): an adapter file in the format the
+    reference's dreambooth.py writes (`<layer>.lora_a` [in,r], `.lora_b` [r,out], metadata lora_rank / lora_blocks)
+    is folded into the flow weights by one GEMM per layer: W' = W + (lora_b^T @ lora_a^T).astype(bf16), then the
+    forward must match the oracle evaluated with W'."""
+    import warnings
+    from safetensors.torch import save_file
+    from flux_generator_amd.flux.flux import FluxPipeline
+    _tiny_flux_zoo(monkeypatch)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe = FluxPipeline("flux-schnell", device=str(dev))
+    flow = pipe.flow
+    P = flow.params
+    targets = ["single_blocks.1.linear1", "single_blocks.1.linear2", "single_blocks.1.modulation.lin",
+               "double_blocks.1.img_attn.qkv", "double_blocks.1.txt_attn.proj", "double_blocks.1.img_mlp.layers.0",
+               "double_blocks.1.txt_mlp.layers.2", "double_blocks.1.img_mod.lin"]
+    g = torch.Generator().manual_seed(0)
+    before = {n: flow.parameters()[f"{n}.weight"].clone() for n in targets}
+    untouched = flow.parameters()["double_blocks.0.img_attn.qkv.weight"].clone()
+    adapter = {}
+    for n in targets:
+        out_d, in_d = before[n].shape
+        adapter[f"{n}.lora_a"] = (torch.randn(in_d, 8, generator=g) * in_d ** -0.5).to(BF)
+        adapter[f"{n}.lora_b"] = (torch.randn(8, out_d, generator=g) * 0.05).to(BF)
+    f = str(tmp_path / "final_adapters.safetensors")
+    save_file(adapter, f, metadata={"lora_rank": "8", "lora_blocks": "2"})
+    assert pipe.load_adapter(f, fuse=True) == len(targets)
+    for n in targets:
+        delta = (adapter[f"{n}.lora_b"].float().t() @ adapter[f"{n}.lora_a"].float().t()).to(BF)      # (B^T A^T).astype(bf16)
+        want = (before[n].float().cpu() + delta.float()).to(BF)
+        got = flow.parameters()[f"{n}.weight"].cpu()
+        assert not torch.equal(got, before[n].cpu())
+        assert (got.float() - want.float()).abs().max() <= 2 * want.float().abs().max() * 2 ** -8, n    # <= 1 bf16 ulp
+    assert torch.equal(flow.parameters()["double_blocks.0.img_attn.qkv.weight"], untouched)
+    # forward with the fused weights == oracle with the fused weights
+    OP = O.FluxParams(in_channels=P.in_channels, vec_in_dim=P.vec_in_dim, context_in_dim=P.context_in_dim,
+                      hidden_size=P.hidden_size, mlp_ratio=P.mlp_ratio, num_heads=P.num_heads, depth=P.depth,
+                      depth_single_blocks=P.depth_single_blocks, axes_dim=P.axes_dim, theta=P.theta, qkv_bias=True,
+                      guidance_embed=False)
+    W = {k: v.float().cpu() for k, v in flow.parameters().items()}
+    z = torch.randn(1, 16, 16, 16, generator=g).to(BF)
+    img, ids = O.prepare_latent_images(z)
+    txt = (torch.randn(1, 32, P.context_in_dim, generator=g) * 0.5).to(BF)
+    tids = torch.zeros(1, 32, 3, dtype=torch.int32)
+    vec = torch.randn(1, P.vec_in_dim, generator=g).to(BF)
+    t = torch.full((1,), 0.5, dtype=BF)
+    ref = O.flux_forward(OP, W, img.float(), ids, txt.float(), tids, t, vec.float())
+    got = flow(img.to(dev), ids.to(dev), txt.to(dev), tids.to(dev), t.to(dev), vec.to(dev))
+    assert rel_l2(got, ref) < 1e-2
+    bad = dict(adapter)
+    bad["single_blocks.9.linear1.lora_a"] = bad["single_blocks.1.linear1.lora_a"]
+    bad["single_blocks.9.linear1.lora_b"] = bad["single_blocks.1.linear1.lora_b"]
+    with pytest.raises(ValueError):
+        flow.fuse_lora(bad)

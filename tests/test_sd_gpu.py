@@ -172,7 +172,7 @@ def test_sd_vae_decode_tiny(dev):
     assert rel_l2(ae.decode(z.to(dev), precision="bf16"), S.vae_decode(ocfg, W, z.float())) < 2e-2
 
 
-def test_sdxl_pipeline_surface(dev):
+def test_sdxl_pipeline_surface(dev, monkeypatch):
     """StableDiffusionXL.generate_latents / decode drive end to end on a (patched-in) tiny model."""
     import warnings
     from flux_generator_amd import stable_diffusion as sd
@@ -185,9 +185,19 @@ def test_sdxl_pipeline_surface(dev):
         kw.update(cross_attention_dim=(768 + 1280,) * 2, projection_class_embeddings_input_dim=1280 + 6 * 32)
         model_io._MODELS[key].update(unet_config=UNetConfig(**kw),
                                      vae_config=AutoencoderConfig(block_out_channels=(128, 128), layers_per_block=1))
+        # the REAL text path (both CLIP text transformers on libfluxhip, hidden_states[-2] of each concatenated,
+        # pooled text_projection of encoder 2) at the real widths 768 / 1280, with 2 layers each to keep the test short
+        for mk in ("text_encoder", "text_encoder_2"):
+            monkeypatch.setitem(model_io._TEXT_CONFIGS, (key, mk), {**model_io._TEXT_CONFIGS[(key, mk)], "num_layers": 2})
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             pipe = sd.StableDiffusionXL(key, float16=True, device=str(dev))
+        from flux_generator_amd.stable_diffusion.clip import CLIPTextModel
+        assert isinstance(pipe.text_encoder_1, CLIPTextModel) and isinstance(pipe.text_encoder_2, CLIPTextModel)
+        cond, pooled = pipe._get_text_conditioning("a photo of a cat", n_images=2, cfg_weight=0.0)
+        assert cond.shape[0] == 2 and cond.shape[2] == 768 + 1280 and pooled.shape == (2, 1280)
+        c2, _ = pipe._get_text_conditioning("a photo of a dog", n_images=2, cfg_weight=0.0)
+        assert not torch.equal(cond, c2), "conditioning does not depend on the prompt"
         lat = list(pipe.generate_latents("a photo of a cat", n_images=2, num_steps=2, cfg_weight=0.0,
                                          latent_size=(16, 16), seed=3))
         assert len(lat) == 2 and lat[-1].shape == (2, 16, 16, 4) and bool(torch.isfinite(lat[-1].float()).all())

@@ -94,3 +94,33 @@ def test_clip_text_model_tiny(dev):
     assert rel_l2(got.pooled_output, ref.pooled_output) < 1.5e-2
     assert rel_l2(got.hidden_states[-2], ref.hidden_states[-2]) < 1.5e-2
     assert got.pooled_output.shape == (2, 128)
+
+
+@pytest.mark.parametrize("act,proj", [("gelu", 96), ("gelu", None), ("quick_gelu", 64)])
+def test_sd_clip_text_model_tiny(dev, act, proj):
+    """stable_diffusion/ text encoders: exact-erf gelu towers (SD 2.1, SDXL encoder 2), text_projection on the pooled
+    row, hidden_states[-2] (what SDXL conditions on) vs the oracle pinned to transformers."""
+    from flux_generator_amd.stable_diffusion.clip import CLIPTextModel, CLIPTextModelConfig
+    kw = dict(num_layers=3, model_dims=128, num_heads=2, max_length=77, vocab_size=300, hidden_act=act, projection_dim=proj)
+    ocfg = T.CLIPTextModelConfig(**kw)
+    W = {k: v.to(BF).float() for k, v in O.init_weights(T.clip_weight_shapes(ocfg), seed=4, norm_jitter=0.2).items()}
+    for k in ("token_embedding.weight", "position_embedding.weight"):
+        W[k] = (torch.randn(W[k].shape, generator=torch.Generator().manual_seed(5)) * 0.5).to(BF).float()
+    model = CLIPTextModel(CLIPTextModelConfig(**kw), device=dev).load_weights(W)
+    tokens = torch.randint(1, 298, (2, 13), generator=torch.Generator().manual_seed(6))
+    tokens[:, 0] = 298
+    tokens[0, 6:] = 0                 # the SD pipelines pad with 0 (__init__.py:44), EOS = 299 stays the argmax
+    tokens[0, 5] = 299
+    tokens[1, 12] = 299
+    got = model(tokens)
+    ref = T.clip_text_model(ocfg, W, tokens)
+    assert rel_l2(got.last_hidden_state, ref.last_hidden_state) < 1.5e-2
+    assert rel_l2(got.hidden_states[-2], ref.hidden_states[-2]) < 1.5e-2
+    assert got.pooled_output.shape == (2, proj or 128) and rel_l2(got.pooled_output, ref.pooled_output) < 1.5e-2
+
+
+def test_gelu_erf_epilogue(dev):
+    from flux_generator_amd import ops
+    n, w, b = rnd(40, 128, seed=5), rnd(256, 128, seed=6, scale=0.1), rnd(256, seed=7)
+    ref = torch.nn.functional.gelu(O.linear(n.float().cpu(), w.float().cpu(), b.float().cpu()))
+    assert rel_l2(ops.linear(n, w, b, epi=ops.EPI_GELU_ERF), ref) < 4e-3

@@ -68,6 +68,42 @@ def test_clip_vs_transformers():
     assert rel_l2(got.hidden_states[-2], hfo.hidden_states[-2]) < 1e-5
 
 
+def test_sd_clip_with_projection_vs_transformers():
+    """The stable_diffusion/ variant (stable_diffusion/stable_diffusion/clip.py): exact-erf "gelu" tower with the
+    bias-free text_projection on the pooled EOS row, against transformers' CLIPTextModelWithProjection, through the
+    product's map_clip_text_encoder_weights (pure key mapping)."""
+    tr = pytest.importorskip("transformers")
+    hf_cfg = tr.CLIPTextConfig(vocab_size=120, hidden_size=128, intermediate_size=512, num_hidden_layers=3,
+                               num_attention_heads=2, max_position_embeddings=20, hidden_act="gelu", projection_dim=96,
+                               eos_token_id=119, bos_token_id=118, pad_token_id=119)
+    torch.manual_seed(2)
+    hf = tr.CLIPTextModelWithProjection(hf_cfg).eval()
+    from flux_generator_amd.stable_diffusion.clip import map_clip_text_encoder_weights
+    W = {}
+    for k, v in hf.state_dict().items():
+        if "position_ids" not in k:
+            W.update(map_clip_text_encoder_weights(k, v))
+    cfg = T.CLIPTextModelConfig(num_layers=3, model_dims=128, num_heads=2, max_length=20, vocab_size=120, hidden_act="gelu",
+                                projection_dim=96)
+    assert set(T.clip_weight_shapes(cfg)) == set(W)
+    tokens = torch.randint(0, 118, (2, 12))
+    tokens[:, 0] = 118
+    tokens[0, 7:] = 119
+    tokens[1, 11] = 119
+    with torch.no_grad():
+        hfo = hf(input_ids=tokens, output_hidden_states=True)
+        got = T.clip_text_model(cfg, W, tokens)
+    assert rel_l2(got.last_hidden_state, hfo.last_hidden_state) < 1e-5
+    assert got.pooled_output.shape == (2, 96) and rel_l2(got.pooled_output, hfo.text_embeds) < 1e-5
+    assert rel_l2(got.hidden_states[-2], hfo.hidden_states[-2]) < 1e-5
+    # the product's config parser: projection only for "...WithProjection" checkpoints (model_io.py:246-257)
+    from flux_generator_amd.flux.clip import CLIPTextModelConfig as PC
+    d = dict(num_hidden_layers=3, hidden_size=128, num_attention_heads=2, max_position_embeddings=20, vocab_size=120,
+             hidden_act="gelu", projection_dim=96)
+    assert PC.from_dict({**d, "architectures": ["CLIPTextModelWithProjection"]}).projection_dim == 96
+    assert PC.from_dict({**d, "architectures": ["CLIPTextModel"]}).projection_dim is None
+
+
 def test_relative_position_buckets_kat():
     b = T.relative_position_bucket(torch.arange(-40, 41), True, 32, 128)
     assert int(b[40]) == 0 and int(b[41]) == 17 and int(b[39]) == 1          # 0, +1 (offset 16), -1

@@ -58,8 +58,6 @@ def main(argv=None):
     args.steps = args.steps or (50 if args.model == "dev" else 2)
     if not torch.cuda.is_available():
         sys.exit("txt2image.py needs an MI355X (HIP) device: the denoise/decode path has no CPU fallback")
-    if args.adapter:
-        sys.exit("--adapter: LoRA adapters are a training-side feature that is out of this build's scope")
     if args.quantize:
         print("Note: --quantize (MLX 4/8-bit nn.quantize) has no effect here; weights stay bf16")
 
@@ -77,6 +75,9 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=torch.device(device))
     flux = FluxPipeline("flux-" + args.model, t5_padding=args.t5_padding, device=device)
     dev = flux.device
+    if args.adapter:
+        n = flux.load_adapter(args.adapter, fuse=args.fuse_adapter)
+        print(f"Applied LoRA adapter {args.adapter} to {n} layers", file=sys.stderr)
     if args.preload_models:
         flux.ensure_models_are_loaded()
 
