@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0    # dense, block-scaled K=128 fp8 MFMA (same guide)
 
 
 def flux_forward_flops(L: int, S: int, D: int = 3072, depth: int = 19, singles: int = 38) -> float:
@@ -79,7 +80,7 @@ def pmc_traffic(label: str) -> dict:
     import csv, re
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.csv")
     m = re.search(r"cfg(\d+)", label)
-    if not m or not os.path.exists(path):
+    if not m or "fp8" in label or not os.path.exists(path):
         return {"traffic": None}
     import ctypes
     from flux_generator_amd import _lib
@@ -104,14 +105,19 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
-    ap.add_argument("--image-size", type=int, default=512)
-    ap.add_argument("--denoise-steps", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 1; 4 with --fp8)")
+    ap.add_argument("--image-size", type=int, default=None, help="default 512; 1024 with --fp8")
+    ap.add_argument("--denoise-steps", type=int, default=None, help="default 2; 4 with --fp8")
     ap.add_argument("--model", default="flux-schnell", help="flux-schnell (headline) or flux-dev (BASELINE.json configs[2])")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4]: e4m3 weights + per-token e4m3 activations on the "
+                    "fp8 matrix cores; defaults become 1024x1024, 4 denoise steps, batch 4 per GPU")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="run a few steps for rocprofv3, print nothing else")
     args = ap.parse_args()
+    args.batch = args.batch or (4 if args.fp8 else 1)
+    args.image_size = args.image_size or (1024 if args.fp8 else 512)
+    args.denoise_steps = args.denoise_steps or (4 if args.fp8 else 2)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +136,9 @@ def main() -> None:
     import warnings
     warnings.simplefilter("ignore")
     pipe = FluxPipeline(args.model, device=str(dev), use_graph=not args.no_graph)
+    if args.fp8:
+        pipe.flow.enable_fp8()
+    peak = MFMA_FP8_PEAK_TFLOPS if args.fp8 else MFMA_BF16_PEAK_TFLOPS
 
     B = args.batch
     lat = args.image_size // 8
@@ -221,7 +230,7 @@ def main() -> None:
     n, ms, fl = by[dom]
     ach = fl / (ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": dom, "launches_per_forward": n, "avg_launch_ms": ms / n,
-                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "algorithmic_flop_per_launch": fl / n}
     roofline.update(pmc_traffic(dom))
     breakdown = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": (round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None)}
@@ -234,7 +243,9 @@ def main() -> None:
             "metric": f"images/sec, {args.model.replace('flux-', 'Flux-')} {args.image_size}x{args.image_size} {args.denoise_steps}-step (denoise-step ms in config)",
             "value": total_images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp8 e4m3 (block Linears: weights per-channel, activations per-token; residual stream / attention / VAE as in bf16 mode)" if args.fp8 else "bf16",
+            "data": "synthetic",
             "config": {"workload": f"{args.model.replace('flux-', 'Flux-')} {args.image_size}x{args.image_size} {args.denoise_steps}-step, "
                                    f"batch {B}/GPU, random-init weights, synthetic x_T/txt/vec resident in HBM; "
                                    "per step: 2 x (Flux forward + Euler) + VAE decode",
@@ -242,7 +253,7 @@ def main() -> None:
                        "denoise_step_ms": step_ms, "vae_decode_ms": decode_ms["fp32"],
                        "vae_precision": "fp32-faithful, like the reference's fp32 AE (bf16 hi/lo planes, 3 MFMA passes, fp32 accumulate / norms / softmax)",
                        "vae_decode_ms_bf16_storage_optin": decode_ms["bf16"],
-                       "flux_forward_tflop_per_image": fwd_tflop, "denoise_mfma_frac": B * fwd_tflop / (step_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
+                       "flux_forward_tflop_per_image": fwd_tflop, "denoise_mfma_frac": B * fwd_tflop / (step_ms * 1e-3) / peak,
                        "hip_graph": not args.no_graph, "kernel_breakdown_one_forward": breakdown},
             "roofline": roofline,
         }

@@ -49,6 +49,10 @@ class GemmX3Desc(C.Structure):
     ]
 
 
+class Fp8Scales(C.Structure):
+    _fields_ = [("a_scale", c_void_p * 2), ("w_scale", c_void_p * 2), ("a_scale_bstride", c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/fluxhip.h declares
 SIGNATURES = {
     "fluxhip_abi_version": (c_int, []),
@@ -86,6 +90,11 @@ SIGNATURES = {
     "fluxhip_rmsnorm_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_float, c_void_p]),
     "fluxhip_embedding_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "fluxhip_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    # fp8 path
+    "fluxhip_quantize_rows_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "fluxhip_quantize_rows_fp8_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "fluxhip_gemm_fp8": (c_int, [C.POINTER(GemmDesc), C.POINTER(Fp8Scales), c_void_p]),
+    "fluxhip_gemm_fp8_tile_cfg": (c_int, [C.POINTER(GemmDesc)]),
     # fp32-faithful ("bf16x3") VAE path
     "fluxhip_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "fluxhip_join_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

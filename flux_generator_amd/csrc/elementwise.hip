@@ -471,6 +471,61 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_x3_kernel(const bf16_t* __
   }
 }
 
+
+// ---- fp8 (e4m3fn) row quantiser: one 256-thread block per row, the row stays in registers between the amax
+// reduction and the conversion (K <= 16384)
+template <bool F32SRC>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const void* __restrict__ x, uint8_t* __restrict__ out,
+                                                                float* __restrict__ scale, int K, long long ld) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const int tid = threadIdx.x, nch = K >> 3;           // 8-element chunks
+  constexpr int MAXC = 8;                              // chunks per thread: K <= 8 * 256 * 8
+  float v[MAXC][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * 256;
+    if (c < nch) {
+      if constexpr (F32SRC) {
+        const float* p = (const float*)x + row * ld + c * 8;
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = b[e]; }
+      } else {
+        const u32x4 w = *(const u32x4*)((const bf16_t*)x + row * ld + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][2 * e] = bf_lo(w[e]); v[i][2 * e + 1] = bf_hi(w[e]); }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+    }
+  }
+  amax = wave_max(amax);
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / sc;
+  if (tid == 0) scale[row] = sc;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * 256;
+    if (c < nch) {
+      u32x2 o;
+      int w0 = 0, w1 = 0;
+      // v_cvt_pk_fp8_f32: two floats -> two OCP e4m3fn bytes (round to nearest even), packed into the selected half
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4] * inv, v[i][5] * inv, w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][6] * inv, v[i][7] * inv, w1, true);
+      o[0] = (uint32_t)w0;
+      o[1] = (uint32_t)w1;
+      *(u32x2*)(out + row * (long long)K + c * 8) = o;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int fluxhip_euler_step_bf16(const void* x, const void* pred, void* out, int64_t n,
@@ -623,5 +678,22 @@ extern "C" int fluxhip_conv2d_small_x3(const void* x, int64_t x_lo, const void* 
   else if (Cin == 256) FEWOUT3(32);
   else FEWOUT3(64);
 #undef FEWOUT3
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+// ---- fp8 row quantiser entry points ---------------------------------------------------------------
+extern "C" int fluxhip_quantize_rows_fp8(const void* x, void* out, void* scale, int64_t rows, int K, int64_t ld,
+                                         void* stream) {
+  if (!x || !out || !scale || rows < 1 || K < 16 || K % 16 || K > 16384 || ld < K || ld % 8) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL((quantize_rows_fp8_kernel<false>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x,
+                     (uint8_t*)out, (float*)scale, K, (long long)ld);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_quantize_rows_fp8_f32(const void* x, void* out, void* scale, int64_t rows, int K, int64_t ld,
+                                             void* stream) {
+  if (!x || !out || !scale || rows < 1 || K < 16 || K % 16 || K > 16384 || ld < K || ld % 4) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL((quantize_rows_fp8_kernel<true>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x,
+                     (uint8_t*)out, (float*)scale, K, (long long)ld);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }

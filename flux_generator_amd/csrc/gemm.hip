@@ -12,13 +12,14 @@ struct TileCfg {
   void (*conv)(const GemmParams);
   void (*dense_x3)(const GemmParams);   // FLAG_SPLIT (bf16x3, fp32-faithful) instantiations; null for most tiles
   void (*conv_x3)(const GemmParams);
+  void (*dense_f8)(const GemmParams);   // FLAG_FP8 (e4m3 x e4m3 on the 16x16x128 block-scaled MFMA); simple-ring and ping-pong tiles
 };
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE, int FLAGS = 0>
 constexpr TileCfg make_cfg() {
   return TileCfg{BM, BN, WM * WN * 64, (NSTAGE * BM + (PIPE >= 3 ? NSTAGE + 1 : NSTAGE) * BN) * 64 * 2,
                  gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAGS>,
-                 gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE, FLAGS>, nullptr, nullptr};
+                 gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE, FLAGS>, nullptr, nullptr, nullptr};
 }
 // the same tile with the fp32-faithful (FLAG_SPLIT) kernels as well: only the tiles the VAE decoders use
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
@@ -28,14 +29,26 @@ constexpr TileCfg make_cfg_x3() {
   c.conv_x3 = gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE, FLAG_SPLIT>;
   return c;
 }
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
+constexpr TileCfg make_cfg_f8() {
+  TileCfg c = make_cfg<BM, BN, WM, WN, NSTAGE, PIPE>();
+  c.dense_f8 = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_FP8>;
+  return c;
+}
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
+constexpr TileCfg make_cfg_x3_f8() {
+  TileCfg c = make_cfg_x3<BM, BN, WM, WN, NSTAGE, PIPE>();
+  c.dense_f8 = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_FP8>;
+  return c;
+}
 
 // index 0 is unused ("auto")
 const TileCfg kCfgs[] = {
-    TileCfg{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr},
-    make_cfg<128, 128, 2, 2, 2, 0>(),  // 1: 64 KiB LDS, 2 blocks/CU
-    make_cfg<128, 64, 2, 2, 2, 0>(),   // 2: more blocks for N=3072 outputs at small M
-    make_cfg<64, 128, 2, 2, 2, 0>(),   // 3
-    make_cfg_x3<64, 64, 2, 2, 2, 0>(),    // 4: tiny problems (N=64 final layer)
+    TileCfg{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr},
+    make_cfg_f8<128, 128, 2, 2, 2, 0>(),  // 1: 64 KiB LDS, 2 blocks/CU
+    make_cfg_f8<128, 64, 2, 2, 2, 0>(),   // 2: more blocks for N=3072 outputs at small M
+    make_cfg_f8<64, 128, 2, 2, 2, 0>(),   // 3
+    make_cfg_x3_f8<64, 64, 2, 2, 2, 0>(),    // 4: tiny problems (N=64 final layer)
     make_cfg<256, 128, 4, 2, 2, 0>(),  // 5: 8 waves, 96 KiB
     make_cfg<256, 256, 2, 4, 2, 0>(),  // 6: 8 waves x (128x64), 128 KiB
     make_cfg_x3<128, 128, 2, 2, 2, 1>(),  // 7: fragment-pipelined variants of 1,2,3,5,6
@@ -83,14 +96,14 @@ const TileCfg kCfgs[] = {
     make_cfg_x3<256, 256, 4, 2, 2, 6>(),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
     make_cfg<256, 224, 4, 2, 2, 6>(),     // 50: cfg 44 "
     make_cfg<256, 192, 4, 2, 2, 6>(),     // 51: cfg 45 "
-    make_cfg<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
-    make_cfg<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
-    make_cfg<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
-    make_cfg_x3<128, 256, 2, 4, 2, 6>(),     // 55: 128x256, ping-pong
+    make_cfg_f8<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
+    make_cfg_f8<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
+    make_cfg_f8<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
+    make_cfg_x3_f8<128, 256, 2, 4, 2, 6>(),     // 55: 128x256, ping-pong
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-bool g_attr_set[kNumCfgs][4] = {};
+bool g_attr_set[kNumCfgs][5] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
 // Tile choice: time model fitted to tools/gemm_tune.py sweeps (profiles/r01_gemm_tune_*.txt):
@@ -134,6 +147,15 @@ const Cand kX3ConvCands[] = {
     {8, 2, 0.847f, 0.30f}, {9, 2, 0.672f, 2.90f}, {4, 2, 0.483f, 1.15f},
 };
 
+// fp8 kernels: the ping-pong tiles (time per K-step as measured for bf16: a K-step is the same 128 bytes per row) and
+// the simple-ring tiles for small shapes.
+// (the 256x256 / 256x224 / 256x192 ping-pong tiles do not fit 256 registers with 8-register fp8 operand tuples and
+//  spill: a spilled LDS-read destination is copied before the data lands, so they are not instantiated for fp8)
+const Cand kF8Cands[] = {
+    {54, 1, 0.819f, 14.3f}, {52, 1, 0.760f, 12.1f}, {55, 1, 0.787f, 10.9f}, {53, 1, 0.600f, 6.0f},  {1, 2, 1.000f, 10.2f},
+    {2, 2, 0.847f, 0.30f},  {3, 2, 0.672f, 2.90f},  {4, 2, 0.483f, 1.15f},
+};
+
 // Split-K workspace (fluxhip_set_workspace): [kSkMaxTiles] int32 hand-off counters, then fp32 partial tiles.
 constexpr int kSkMaxTiles = 16384;
 char* g_ws = nullptr;
@@ -166,7 +188,9 @@ int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbat
   return best_cfg;
 }
 
-int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool conv = false, bool x3 = false) {
+int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool conv = false, bool x3 = false,
+             bool f8 = false) {
+  if (f8) return pick_from(kF8Cands, group_m, ngroups, nbatch, N, K / 2);   // 128 elements per K-step
   if (x3)   // three passes over K
     return conv ? pick_from(kX3ConvCands, group_m, ngroups, nbatch, N, 3 * K)
                 : pick_from(kX3Cands, group_m, ngroups, nbatch, N, 3 * K);
@@ -174,7 +198,7 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
               : pick_from(kCands, group_m, ngroups, nbatch, N, K);
 }
 
-int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false) {
+int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false, bool f8 = false) {
   const int cfg_idx = cfg_code & 0xff;
   int splits = cfg_code >> 8;
   if (splits < 1) splits = 1;
@@ -188,9 +212,9 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
   if (p.ngroups == 1) p.g[1] = p.g[0];
   p.tiles_m_total = tm_total;
   p.tiles_n = (p.N + c.bn - 1) / c.bn;
-  auto fn = x3 ? (conv ? c.conv_x3 : c.dense_x3) : (conv ? c.conv : c.dense);
-  if (!fn) return FLUXHIP_EINVAL;                   // this tile has no fp32-faithful instantiation
-  const int slot = (int)conv + 2 * (int)x3;
+  auto fn = f8 ? c.dense_f8 : x3 ? (conv ? c.conv_x3 : c.dense_x3) : (conv ? c.conv : c.dense);
+  if (!fn) return FLUXHIP_EINVAL;                   // this tile has no fp32-faithful / fp8 instantiation
+  const int slot = f8 ? 4 : (int)conv + 2 * (int)x3;
   if (!g_attr_set[cfg_idx][slot]) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) !=
         hipSuccess)
@@ -211,7 +235,7 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
   p.splits = splits;
   if (splits > 1) {
     const long long tiles = (long long)tm_total * p.tiles_n;
-    if (splits > (x3 ? 3 : 1) * (p.K / 64) || tiles > kSkMaxTiles ||
+    if (splits > (f8 ? p.K / 128 : (x3 ? 3 : 1) * (p.K / 64)) || tiles > kSkMaxTiles ||
         (long long)kSkMaxTiles * 4 + tiles * c.bm * c.bn * 4LL > g_ws_bytes)
       return FLUXHIP_EINVAL;                        // no (or too small a) split-K workspace
     p.sk_flag = (int*)g_ws;
@@ -224,12 +248,11 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
 
 }  // namespace
 
-extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
+// fluxhip_gemm_desc -> GemmParams (shared by the bf16 and the fp8 entry points); kalign = K granularity
+static int params_from_desc(const fluxhip_gemm_desc* d, GemmParams& p, int kalign) {
   if (!d || d->ngroups < 1 || d->ngroups > 2 || d->nbatch < 1) return FLUXHIP_EINVAL;
-  if (d->K <= 0 || d->K % 64 || d->N <= 0 || d->N % 4 || d->lda % 8 || d->ldc % 4)
+  if (d->K <= 0 || d->K % kalign || d->N <= 0 || d->N % 4 || d->lda % (kalign == 128 ? 16 : 8) || d->ldc % 4)
     return FLUXHIP_EINVAL;
-  GemmParams p{};
-  long long m_total = 0;
   for (int g = 0; g < d->ngroups; ++g) {
     const fluxhip_gemm_group& s = d->g[g];
     if (!s.A || !s.W || !s.C || s.M <= 0) return FLUXHIP_EINVAL;
@@ -246,7 +269,6 @@ extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
     t.gate_bstride = s.gate_bstride;
     t.w_bstride = s.w_bstride;
     t.M = s.M;
-    m_total += (long long)s.M * d->nbatch;
   }
   if (d->epi == FLUXHIP_EPI_SPLIT_GELU && (!d->C2 || d->n_split % 4 || d->ldc2 % 4 || d->c2_coloff % 4))
     return FLUXHIP_EINVAL;
@@ -266,9 +288,38 @@ extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.out_f32 = d->out_f32;
   if (p.out_f32 && d->epi != FLUXHIP_EPI_BIAS) return FLUXHIP_EINVAL;
+  return FLUXHIP_OK;
+}
+
+extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
+  GemmParams p{};
+  if (int rc = params_from_desc(d, p, 64)) return rc;
   const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
   int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K);
   return launch(p, cfg, false, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_gemm_fp8(const fluxhip_gemm_desc* d, const fluxhip_fp8_scales* sc, void* stream) {
+  GemmParams p{};
+  if (!sc) return FLUXHIP_EINVAL;
+  if (int rc = params_from_desc(d, p, 128)) return rc;
+  for (int g = 0; g < d->ngroups; ++g) {
+    if (!sc->a_scale[g] || !sc->w_scale[g]) return FLUXHIP_EINVAL;
+    p.a_scale[g] = (const float*)sc->a_scale[g];
+    p.w_scale[g] = (const float*)sc->w_scale[g];
+  }
+  if (d->ngroups == 1) { p.a_scale[1] = p.a_scale[0]; p.w_scale[1] = p.w_scale[0]; }
+  p.a_sc_bstride = sc->a_scale_bstride;
+  const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
+  int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K, false, false, true);
+  return launch(p, cfg, false, (hipStream_t)stream, false, true);
+}
+
+extern "C" int fluxhip_gemm_fp8_tile_cfg(const fluxhip_gemm_desc* d) {
+  if (!d || d->ngroups < 1 || d->ngroups > 2) return FLUXHIP_EINVAL;
+  if (d->tile_cfg > 0) return d->tile_cfg < kNumCfgs ? d->tile_cfg : FLUXHIP_EINVAL;
+  const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
+  return pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K, false, false, true);
 }
 
 extern "C" int fluxhip_gemm_x3(const fluxhip_gemm_x3_desc* d, void* stream) {

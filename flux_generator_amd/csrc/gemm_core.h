@@ -90,6 +90,12 @@ struct GemmParams {
   // of bf16 planes (hi = bf16(x), lo = bf16(x - hi)); the lo plane sits `*_lo` ELEMENTS after the hi pointer.
   // bias is float32.  See the FLAG_SPLIT note at the kernel.
   long long a_lo, w_lo, c_lo, res_lo;
+  // FLAG_FP8 kernels only: per-row dequantisation scales of the fp8 (e4m3fn) operands, per group:
+  // C = (acc * a_scale[m] * w_scale[n]) + bias.  a_scale is indexed like the rows of A ([nbatch][M], batch stride
+  // a_sc_bstride), w_scale like the rows of W ([N]).
+  const float* a_scale[2];
+  const float* w_scale[2];
+  long long a_sc_bstride;
 };
 
 enum GemmFlags : int {
@@ -102,6 +108,14 @@ enum GemmFlags : int {
   // runs over 3 * K/64 steps, g -> (operand step g / 3, pass g % 3), and the pass only selects which plane the
   // staging addresses point at (the hi tiles are fetched twice back to back: the second fetch hits L2).
   FLAG_SPLIT = 2,
+  // fp8 operands on the block-scaled matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4, the only fp8 MFMA
+  // that runs at twice the bf16 rate on gfx950; unit E8M0 block scales).  A and W are OCP e4m3fn bytes with one
+  // float32 scale per row (per token / per output channel), applied in the epilogue.  A K-step is still 128 BYTES
+  // per row (128 fp8 elements instead of 64 bf16), so the LDS image, the LDS-DMA staging, the swizzle and the whole
+  // barrier / vmcnt schedule are those of the bf16 kernel; only the fragment chunk pairing differs: a lane's 32
+  // consecutive K bytes are the two 16-byte chunks 2q and 2q+1 of its row (bf16: chunk q for MFMA 0, 4+q for MFMA 1),
+  // and the pair feeds ONE 16x16x128 MFMA where the bf16 loop issues two 16x16x32.  Same cycles per K-step, 2x K.
+  FLAG_FP8 = 4,
 };
 
 template <int N>
@@ -184,7 +198,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   const int n0 = tn * BN;
   const int N = p.N, K = p.K;
   constexpr bool X3 = (FLAGS & FLAG_SPLIT) != 0;
-  const int nkt_all = X3 ? 3 * (K / BK) : K / BK;
+  constexpr bool F8 = (FLAGS & FLAG_FP8) != 0;
+  constexpr int ESZ = F8 ? 1 : 2;                  // bytes per operand element
+  static_assert(!(F8 && (X3 || AMODE != 0)), "fp8: dense operands, no split mode");
+  static_assert(!F8 || PIPE == 0 || PIPE == 6, "fp8 variants exist for the simple ring and the ping-pong schedule");
+  const int nkt_all = X3 ? 3 * (K / BK) : K / (BK * 2 / ESZ);
   // K range of this block (even split; skewing the ranges so that the producer finishes early did not
   // pay: the release fence of the early block slows the L2 for the blocks still in their main loop)
   const int kbase = (int)((long long)sidx * nkt_all / S);
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     int row = (wave + i * NWAVES) * 8 + lr;
     int grow = min(m0 + row, Mg - 1);
     if (AMODE == 0) {
-      asrc[i] = (const char*)(gA + (long long)b * a_bs + (long long)grow * p.lda) + lc * 16;
+      asrc[i] = (const char*)gA + ((long long)b * a_bs + (long long)grow * p.lda) * ESZ + lc * 16;
       arow[i] = 0;
     } else {
       asrc[i] = nullptr;
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   for (int i = 0; i < BPW; ++i) {
     int row = min(wave + i * NWAVES, BPIECES - 1) * 8 + lr;
     int n = min(n0 + row, N - 1);
-    bsrc[i] = (const char*)(gW + (long long)b * w_bs + (long long)n * K) + lc * 16;
+    bsrc[i] = (const char*)gW + ((long long)b * w_bs + (long long)n * K) * ESZ + lc * 16;
   }
 
   // conv geometry decode (per staged row), hoisted out of the K loop, 2 registers per piece (the 256-wide
@@ -336,8 +354,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   // ---- fragment read offsets (same XOR as the staging source swizzle) ---------
   const int r16 = lane & 15, q4 = lane >> 4;
   int foff[2];
-  foff[0] = r16 * 128 + (((0 + q4) ^ (lane & 7)) << 4);
-  foff[1] = r16 * 128 + (((4 + q4) ^ (lane & 7)) << 4);
+  foff[0] = r16 * 128 + (((F8 ? 2 * q4 : q4) ^ (lane & 7)) << 4);
+  foff[1] = r16 * 128 + (((F8 ? 2 * q4 + 1 : 4 + q4) ^ (lane & 7)) << 4);
 
   f32x4 acc[MI][NJ];
 #pragma unroll
@@ -356,6 +374,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
   };
 
+  // FLAG_FP8: the two 16-byte halves of every fragment make one 32-byte operand of the 16x16x128 fp8 MFMA
+  auto mma8 = [&](const bf16x8(&af0)[MI], const bf16x8(&af1)[MI], const bf16x8(&wf0)[NJ], const bf16x8(&wf1)[NJ]) {
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    i32x8 av[MI], wv[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      av[i] = __builtin_shufflevector(__builtin_bit_cast(i32x4, af0[i]), __builtin_bit_cast(i32x4, af1[i]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      wv[j] = __builtin_shufflevector(__builtin_bit_cast(i32x4, wf0[j]), __builtin_bit_cast(i32x4, wf1[j]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv[j], av[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                     0x7f7f7f7f);   // e4m3 x e4m3, unit block scales
+  };
+  auto mma_step = [&](const bf16x8(&af0)[MI], const bf16x8(&wf0)[NJ], const bf16x8(&af1)[MI], const bf16x8(&wf1)[NJ]) {
+    if constexpr (F8) {
+      mma8(af0, af1, wf0, wf1);
+    } else {
+      mma(af0, wf0);
+      mma(af1, wf1);
+    }
+  };
+
   if constexpr (PIPEX == 0) {
     // simple ring: wait -> barrier -> refill the freed slot -> read fragments -> MFMA
 #pragma unroll
@@ -369,6 +414,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       if (kt + NSTAGE - 1 < nkt) { stage_a(kt + NSTAGE - 1, nxt); stage_w(kt + NSTAGE - 1, nxt); }
       const char* sa = smem + cur * A_BYTES + (wm * WTM) * 128;
       const char* sb = smem + W_BASE + cur * B_BYTES + (wn * WTN) * 128;
+      if constexpr (F8) {
+        bf16x8 af0[MI], wf0[NJ], af1[MI], wf1[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          af0[i] = *(const bf16x8*)(sa + i * 2048 + foff[0]);
+          af1[i] = *(const bf16x8*)(sa + i * 2048 + foff[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          wf0[j] = *(const bf16x8*)(sb + j * 2048 + foff[0]);
+          wf1[j] = *(const bf16x8*)(sb + j * 2048 + foff[1]);
+        }
+        mma8(af0, af1, wf0, wf1);
+      } else {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 af[MI], wf[NJ];
@@ -377,6 +436,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
         for (int j = 0; j < NJ; ++j) wf[j] = *(const bf16x8*)(sb + j * 2048 + foff[kk]);
         mma(af, wf);
+      }
       }
       cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
       nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
@@ -456,7 +516,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
           const int row = (lw + i * LW) * 8 + lr;
           const int grow = min(m0 + row, Mg - 1);
           if (AMODE == 0) {
-            src[i] = (const char*)(gA + (long long)b * a_bs + (long long)grow * p.lda) + lc * 16;
+            src[i] = (const char*)gA + ((long long)b * a_bs + (long long)grow * p.lda) * ESZ + lc * 16;
           } else {
             const int hw = p.cv.Ho * p.cv.Wo;
             const int bb = grow / hw, rem = grow - bb * hw;
@@ -523,8 +583,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
           const int sa1 = sa ^ 1, sw1 = sw == 2 ? 0 : sw + 1;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
-          mma(a0, w0);
-          mma(a1, w1);
+          mma_step(a0, w0, a1, w1);
           __builtin_amdgcn_sched_barrier(0);
           wait_vmcnt<0>();                         // my A(kt+1) pieces (issued one phase ago)
           __builtin_amdgcn_s_barrier();            // B1
@@ -542,7 +601,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
           const int row = min(lw + i * LW, BPIECES - 1) * 8 + lr;
-          src[i] = (const char*)(gW + (long long)b * w_bs + (long long)min(n0 + row, N - 1) * K) + lc * 16;
+          src[i] = (const char*)gW + ((long long)b * w_bs + (long long)min(n0 + row, N - 1) * K) * ESZ + lc * 16;
         }
         auto stage = [&](int kt, int slot) {       // W(kt) -> weight slot `slot`
           long long a_adj_unused, w_adj;
@@ -580,8 +639,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slot kt are done before it is refilled
           __builtin_amdgcn_s_barrier();            // B1
           __builtin_amdgcn_sched_barrier(0);
-          mma(a0, w0);
-          mma(a1, w1);
+          mma_step(a0, w0, a1, w1);
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();            // B2
           sa ^= 1;
@@ -859,12 +917,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
     for (int i = 0; i < MI; ++i) brow[i] = rowb ? bf2f(gBias[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)]) : 0.f;
   }
+  // FLAG_FP8: dequantisation scales of this lane's rows (activation, per token) and columns (weight, per channel)
+  float asc[F8 ? MI : 1];
+  f32x4 wsc[F8 ? NJ : 1];
+  if constexpr (F8) {
+    const float* as_ = (g1 ? p.a_scale[1] : p.a_scale[0]) + (long long)b * p.a_sc_bstride;
+    const float* ws_ = g1 ? p.w_scale[1] : p.w_scale[0];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) asc[i] = as_[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)] * alpha;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wsc[j] = *(const f32x4*)(ws_ + min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4));
+  }
   // (ADDVEC is a compile-time tag so the common path carries no per-tile branch or integer division)
   auto biased = [&](auto addvec_tag, int i, int j, int m, int n4, float (&v)[4]) {
+    if constexpr (F8) {
+      v[0] = acc[i][j][0] * (asc[i] * wsc[j][0]) + (bf_lo(bcol[j][0]) + brow[i]);
+      v[1] = acc[i][j][1] * (asc[i] * wsc[j][1]) + (bf_hi(bcol[j][0]) + brow[i]);
+      v[2] = acc[i][j][2] * (asc[i] * wsc[j][2]) + (bf_lo(bcol[j][1]) + brow[i]);
+      v[3] = acc[i][j][3] * (asc[i] * wsc[j][3]) + (bf_hi(bcol[j][1]) + brow[i]);
+    } else {
     v[0] = acc[i][j][0] * alpha + (bf_lo(bcol[j][0]) + brow[i]);
     v[1] = acc[i][j][1] * alpha + (bf_hi(bcol[j][0]) + brow[i]);
     v[2] = acc[i][j][2] * alpha + (bf_lo(bcol[j][1]) + brow[i]);
     v[3] = acc[i][j][3] * alpha + (bf_hi(bcol[j][1]) + brow[i]);
+    }
     if constexpr (decltype(addvec_tag)::value) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
       u32x2 aw = *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
       v[0] = rbf(v[0]) + bf_lo(aw[0]);

@@ -69,6 +69,8 @@ class Flux:
         _lib.load()
         self._alloc_parameters()
         self._ws: Dict[Tuple[int, int, int], dict] = {}
+        self.fp8 = False             # enable_fp8(): e4m3 weights + per-token e4m3 activations on the fp8 matrix cores
+        self._w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # ------------------------------------------------------------------ parameters
     def _alloc_parameters(self) -> None:
@@ -186,6 +188,26 @@ class Flux:
                 raise ValueError(f"Missing parameters: {sorted(missing)[:5]} ...")
         return self
 
+    # ------------------------------------------------------------------ fp8 (BASELINE.json configs[4]; txt2image.py -q)
+    _FP8_LAYERS = ("attn.qkv", "attn.proj", "mlp.layers.0", "mlp.layers.2", "linear1", "linear2")
+
+    def enable_fp8(self, enabled: bool = True) -> "Flux":
+        """The reference's `--quantize` (txt2image.py:26-28,79-82: nn.quantize of the Linears with in_dim % 512 == 0)
+        redesigned for CDNA4: the transformer blocks' Linears (qkv / proj / MLP / linear1 / linear2 = 99.6 % of the
+        forward's FLOPs) get OCP e4m3fn weights with one float32 scale per output channel, their inputs are quantised per
+        token on the fly, and the products run on the block-scaled fp8 MFMA at twice the bf16 rate
+        (include/fluxhip.h, fluxhip_gemm_fp8).  The residual stream, norms, modulation, attention and the small
+        embedders stay bf16.  Weights are quantised once, here; launch plans are rebuilt."""
+        if enabled and not self._w8:
+            for name, w in self._params.items():
+                if name.endswith(".weight") and name[: -len(".weight")].endswith(self._FP8_LAYERS) and w.dim() == 2:
+                    if w.shape[1] % 128:
+                        raise ValueError(f"{name}: fp8 needs in_dim % 128 == 0")
+                    self._w8[name[: -len(".weight")]] = ops.quantize_rows_fp8(w)
+        self.fp8 = bool(enabled)
+        self._ws.clear()
+        return self
+
     def fuse_lora(self, adapter: Dict[str, torch.Tensor], scale: float = 1.0) -> int:
         """LoRA adapters at inference (flux/lora.py:28-43, flux/flux.py:229-246): for every Linear `name` with
         `name.lora_a` [in, r] and `name.lora_b` [r, out] in `adapter`,  W <- W + (scale * lora_b^T @ lora_a^T).astype(bf16).
@@ -238,6 +260,9 @@ class Flux:
             cat=buf(B, T, D + mlp), Q=buf(B, H, T, 128), K=buf(B, H, T, 128), Vt=buf(B, H, 128, Tpad),
             rope=buf(B, T, 64, 2), xl=buf(B, L, D), pred=buf(B, L, P.in_channels),
         )
+        if self.fp8:   # one (e4m3 rows, per-token scale) scratch pair shared by every GEMM input of the step
+            ws["a8"] = buf(B * T, D + mlp, dtype=torch.uint8)
+            ws["asc"] = buf(B * T, dtype=torch.float32)
         ws["plan"] = self._build_plan(ws)
         self._ws[key] = ws
         return ws
@@ -263,6 +288,24 @@ class Flux:
             d = make_gemm_desc(groups, nbatch, N, K, lda, ldc, epi, **kw)
             keep.append(d)
             call(lib.fluxhip_gemm_bf16, ctypes.byref(d))
+
+        def gemm8(src, K, groups, wnames, N, ldc, epi=EPI_BIAS, **kw):   # noqa: E306
+            """fp8 variant of a block Linear over the packed token buffer: quantise the bf16 input rows `src`
+            [B*T, K] per token into the shared scratch, then one fluxhip_gemm_fp8 launch.  `groups` as for gemm() with
+            A given as the ROW offset of the group inside a batch (txt rows first); wnames = weight names per group."""
+            call(lib.fluxhip_quantize_rows_fp8, src, ptr["a8"], ptr["asc"], B * T, K, K)
+            gs, a_sc, w_sc = [], [], []
+            for g, wn in zip(groups, wnames):
+                wq, wscale = self._w8[wn]
+                row0 = g.pop("row0")
+                g.update(A=ptr["a8"] + row0 * K, W=wq.data_ptr(), a_bstride=T * K)
+                gs.append(g)
+                a_sc.append(ptr["asc"] + row0 * 4)
+                w_sc.append(wscale.data_ptr())
+            d = make_gemm_desc(gs, B, N, K, K, ldc, epi, **kw)
+            sc = ops.make_fp8_scales(a_sc, w_sc, T)
+            keep.extend([d, sc])
+            call(lib.fluxhip_gemm_fp8, ctypes.byref(d), ctypes.byref(sc))
 
         def small(x, wn, out, K, N, silu_in, accum):
             call(lib.fluxhip_small_linear_bf16, x, w(wn + ".weight"), wo(wn + ".bias"), out, B, N, K, silu_in, accum)
@@ -314,6 +357,19 @@ class Flux:
                 gs.append(g)
             return gs
 
+        def two_streams8(src, K, C, ldc, c_bs, wname, N, epi=EPI_BIAS, res=None, gate_off=None, i_off=0, t_off=0, prefix=""):
+            gs, wn = [], []
+            for st, row0, M, moff in (("txt", 0, S, t_off), ("img", S, L, i_off)):
+                if M == 0:
+                    continue
+                g = dict(row0=row0, bias=wo(f"{prefix}.{st}_{wname}.bias"), C=C + row0 * ldc * e, c_bstride=c_bs, M=M)
+                if res is not None:
+                    g.update(res=res + row0 * ldc * e, gate=mp + (moff + gate_off) * e, gate_bstride=NM)
+                gs.append(g)
+                wn.append(f"{prefix}.{st}_{wname}")
+            gemm8(src, K, gs, wn, N, ldc, epi)
+
+        F8 = self.fp8
         for i in range(P.depth):                                              # flux/layers.py:181-231
             p = f"double_blocks.{i}"
             if i == JOIN_AT and split_rows < NM:
@@ -321,38 +377,60 @@ class Flux:
             io, to = self.mod_off[f"{p}.img_mod.lin"], self.mod_off[f"{p}.txt_mod.lin"]
             call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, S, T * D, T * D,
                  mp + to * e, mp + (to + D) * e, mp + io * e, mp + (io + D) * e, NM, 1e-6)
-            gemm(two_streams(ptr["xm"], D, T * D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", prefix=p), B, 3 * D, D, D, 3 * D)
+            if F8:
+                two_streams8(ptr["xm"], D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", 3 * D, prefix=p)
+            else:
+                gemm(two_streams(ptr["xm"], D, T * D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", prefix=p), B, 3 * D, D, D, 3 * D)
             call(lib.fluxhip_qk_norm_rope_bf16, ptr["qkv"], 3 * D, B, T, S, H,
                  wo(f"{p}.txt_attn.norm.query_norm.weight"), wo(f"{p}.txt_attn.norm.key_norm.weight"),
                  w(f"{p}.img_attn.norm.query_norm.weight"), w(f"{p}.img_attn.norm.key_norm.weight"),
                  ptr["rope"], T * 128, ptr["Q"], ptr["K"], ptr["Vt"], Tpad, 1e-5)
             call(lib.fluxhip_attention_d128_bf16, ptr["Q"], ptr["K"], ptr["Vt"], ptr["attn"], D, B, H, T, Tpad,
                  128 ** -0.5)
-            gemm(two_streams(ptr["attn"], D, T * D, ptr["x"], D, T * D, "attn.proj", res=ptr["x"], gate_off=2 * D,
-                             i_off=io, t_off=to, prefix=p), B, D, D, D, D, EPI_GATE_RES)
+            if F8:
+                two_streams8(ptr["attn"], D, ptr["x"], D, T * D, "attn.proj", D, EPI_GATE_RES, res=ptr["x"], gate_off=2 * D,
+                             i_off=io, t_off=to, prefix=p)
+            else:
+                gemm(two_streams(ptr["attn"], D, T * D, ptr["x"], D, T * D, "attn.proj", res=ptr["x"], gate_off=2 * D,
+                                 i_off=io, t_off=to, prefix=p), B, D, D, D, D, EPI_GATE_RES)
             call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, S, T * D, T * D,
                  mp + (to + 3 * D) * e, mp + (to + 4 * D) * e, mp + (io + 3 * D) * e, mp + (io + 4 * D) * e, NM, 1e-6)
-            gemm(two_streams(ptr["xm"], D, T * D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", prefix=p), B, mlp, D, D, mlp,
-                 EPI_GELU_TANH)
-            gemm(two_streams(ptr["hmlp"], mlp, T * mlp, ptr["x"], D, T * D, "mlp.layers.2", res=ptr["x"], gate_off=5 * D,
-                             i_off=io, t_off=to, prefix=p), B, D, mlp, mlp, D, EPI_GATE_RES)
+            if F8:
+                two_streams8(ptr["xm"], D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", mlp, EPI_GELU_TANH, prefix=p)
+                two_streams8(ptr["hmlp"], mlp, ptr["x"], D, T * D, "mlp.layers.2", D, EPI_GATE_RES, res=ptr["x"],
+                             gate_off=5 * D, i_off=io, t_off=to, prefix=p)
+            else:
+                gemm(two_streams(ptr["xm"], D, T * D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", prefix=p), B, mlp, D, D, mlp,
+                     EPI_GELU_TANH)
+                gemm(two_streams(ptr["hmlp"], mlp, T * mlp, ptr["x"], D, T * D, "mlp.layers.2", res=ptr["x"], gate_off=5 * D,
+                                 i_off=io, t_off=to, prefix=p), B, D, mlp, mlp, D, EPI_GATE_RES)
 
         for i in range(P.depth_single_blocks):                                # flux/layers.py:262-284
             p = f"single_blocks.{i}"
             o = self.mod_off[f"{p}.modulation.lin"]
             call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, 0, T * D, T * D,
                  None, None, mp + o * e, mp + (o + D) * e, NM, 1e-6)
-            gemm([dict(A=ptr["xm"], W=w(f"{p}.linear1.weight"), bias=wo(f"{p}.linear1.bias"), C=ptr["qkv"],
-                       a_bstride=T * D, c_bstride=T * 3 * D, M=T)], B, 3 * D + mlp, D, D, 3 * D, EPI_SPLIT_GELU,
-                 n_split=3 * D, C2=ptr["cat"], ldc2=D + mlp, c2_bstride=T * (D + mlp), c2_coloff=D)
+            if F8:
+                gemm8(ptr["xm"], D, [dict(row0=0, bias=wo(f"{p}.linear1.bias"), C=ptr["qkv"], c_bstride=T * 3 * D, M=T)],
+                      [f"{p}.linear1"], 3 * D + mlp, 3 * D, EPI_SPLIT_GELU, n_split=3 * D, C2=ptr["cat"], ldc2=D + mlp,
+                      c2_bstride=T * (D + mlp), c2_coloff=D)
+            else:
+                gemm([dict(A=ptr["xm"], W=w(f"{p}.linear1.weight"), bias=wo(f"{p}.linear1.bias"), C=ptr["qkv"],
+                           a_bstride=T * D, c_bstride=T * 3 * D, M=T)], B, 3 * D + mlp, D, D, 3 * D, EPI_SPLIT_GELU,
+                     n_split=3 * D, C2=ptr["cat"], ldc2=D + mlp, c2_bstride=T * (D + mlp), c2_coloff=D)
             call(lib.fluxhip_qk_norm_rope_bf16, ptr["qkv"], 3 * D, B, T, 0, H, None, None,
                  w(f"{p}.norm.query_norm.weight"), w(f"{p}.norm.key_norm.weight"),
                  ptr["rope"], T * 128, ptr["Q"], ptr["K"], ptr["Vt"], Tpad, 1e-5)
             call(lib.fluxhip_attention_d128_bf16, ptr["Q"], ptr["K"], ptr["Vt"], ptr["cat"], D + mlp, B, H, T, Tpad,
                  128 ** -0.5)
-            gemm([dict(A=ptr["cat"], W=w(f"{p}.linear2.weight"), bias=wo(f"{p}.linear2.bias"), C=ptr["x"], res=ptr["x"],
-                       gate=mp + (o + 2 * D) * e, gate_bstride=NM, a_bstride=T * (D + mlp), c_bstride=T * D, M=T)],
-                 B, D, D + mlp, D + mlp, D, EPI_GATE_RES)
+            if F8:
+                gemm8(ptr["cat"], D + mlp, [dict(row0=0, bias=wo(f"{p}.linear2.bias"), C=ptr["x"], res=ptr["x"],
+                                                 gate=mp + (o + 2 * D) * e, gate_bstride=NM, c_bstride=T * D, M=T)],
+                      [f"{p}.linear2"], D, D, EPI_GATE_RES)
+            else:
+                gemm([dict(A=ptr["cat"], W=w(f"{p}.linear2.weight"), bias=wo(f"{p}.linear2.bias"), C=ptr["x"], res=ptr["x"],
+                           gate=mp + (o + 2 * D) * e, gate_bstride=NM, a_bstride=T * (D + mlp), c_bstride=T * D, M=T)],
+                     B, D, D + mlp, D + mlp, D, EPI_GATE_RES)
 
         # LastLayer on the img rows                                           flux/layers.py:298-302
         o = self.mod_off["final_layer.adaLN_modulation.layers.1"]
@@ -404,6 +482,12 @@ class Flux:
                 flops = 2.0 * m_total * d.N * d.K
                 code = lib.fluxhip_gemm_tile_cfg(args[0])      # tile cfg | split-K factor << 8
                 label = f"fluxhip_gemm_bf16/cfg{code & 255}" + (f"s{code >> 8}" if (code >> 8) > 1 else "")
+            elif fn.__name__ == "fluxhip_gemm_fp8":
+                d = args[0]._obj
+                m_total = sum(d.g[i].M for i in range(d.ngroups)) * d.nbatch
+                flops = 2.0 * m_total * d.N * d.K
+                code = lib.fluxhip_gemm_fp8_tile_cfg(args[0])
+                label = f"fluxhip_gemm_fp8/cfg{code & 255}" + (f"s{code >> 8}" if (code >> 8) > 1 else "")
             elif fn.__name__ == "fluxhip_attention_d128_bf16":
                 Bq, Hq, Tq = args[5], args[6], args[7]
                 flops = 4.0 * Bq * Hq * Tq * Tq * 128

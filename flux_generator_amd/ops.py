@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, GemmX3Desc
+from ._lib import Fp8Scales, GemmDesc, GemmX3Desc
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU, EPI_QUICK_GELU, EPI_GELU_ERF = 0, 1, 2, 3, 4, 5, 6, 7
 BF16 = torch.bfloat16
@@ -250,6 +250,51 @@ def softmax_rows(s: torch.Tensor, scale: float, out: Optional[torch.Tensor] = No
         out = torch.zeros(s.shape, dtype=BF16, device=s.device)
     _check(_lib.load().fluxhip_softmax_rows_f32(_p(s), _p(out), rows, cols, ld, float(scale), _stream()),
            "fluxhip_softmax_rows_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ fp8 path
+FP8_MAX = 448.0      # largest finite OCP e4m3fn value
+
+
+def quantize_rows_fp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
+    """x [rows, K] (bf16 or float32, rows contiguous) -> (q uint8 e4m3fn [rows, K], scale float32 [rows]) with
+    scale = max|row| / 448 and q = rne(x / scale): per-token scales for activations, per-output-channel for weights."""
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (BF16, torch.float32):
+        raise FluxHipError("quantize_rows_fp8 takes a 2-D bf16 / float32 tensor with contiguous rows")
+    rows, K = x.shape
+    if out is None:
+        out = torch.empty(rows, K, dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    fn = _lib.load().fluxhip_quantize_rows_fp8 if x.dtype == BF16 else _lib.load().fluxhip_quantize_rows_fp8_f32
+    _check(fn(_p(x), _p(out), _p(scale), rows, K, x.stride(0), _stream()), "fluxhip_quantize_rows_fp8")
+    return out, scale
+
+
+def make_fp8_scales(a_scales, w_scales, a_scale_bstride: int = 0) -> Fp8Scales:
+    """a_scales / w_scales: raw device addresses per group."""
+    sc = Fp8Scales()
+    for i, (a, w) in enumerate(zip(a_scales, w_scales)):
+        sc.a_scale[i], sc.w_scale[i] = a, w
+    sc.a_scale_bstride = a_scale_bstride
+    return sc
+
+
+def gemm_fp8(desc: GemmDesc, scales: Fp8Scales) -> None:
+    _check(_lib.load().fluxhip_gemm_fp8(desc, scales, _stream()), "fluxhip_gemm_fp8")
+
+
+def linear_fp8(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
+               b: Optional[torch.Tensor] = None, epi: int = EPI_BIAS, out: Optional[torch.Tensor] = None,
+               res: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, tile_cfg: int = 0) -> torch.Tensor:
+    """y = epi((xq * x_scale[:, None]) @ (wq * w_scale[:, None]).T + b) on the fp8 matrix cores; y bf16."""
+    M, K = xq.shape
+    N = wq.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=xq.device)
+    g = dict(A=_p(xq), W=_p(wq), bias=_p(b), C=_p(out), res=_p(res), gate=_p(gate), M=M)
+    gemm_fp8(make_gemm_desc([g], 1, N, K, K, N, epi, tile_cfg=tile_cfg), make_fp8_scales([_p(x_scale)], [_p(w_scale)]))
     return out
 
 

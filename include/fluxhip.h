@@ -271,6 +271,30 @@ int fluxhip_unpack_latents_x3(const void* x, void* out, int64_t out_lo, int B, i
 int fluxhip_pixel_linear_x3(const void* x, const void* w, const void* bias, void* out, int64_t out_lo,
                             int64_t npix, int Cin, int Cout, int Cpad, float in_div, void* stream);
 
+/* ---- fp8 weight / activation path (BASELINE.json configs[4]: "Flux-schnell fp8 weights on CDNA4 fp8 MFMA") ------
+ * Replaces the reference's `--quantize` (txt2image.py:26-28,79-82: nn.quantize of every Linear whose input width is
+ * a multiple of 512).  Weights: OCP e4m3fn with one float32 scale per OUTPUT CHANNEL, quantised once at load.
+ * Activations: e4m3fn with one float32 scale per TOKEN (row), quantised on the fly by fluxhip_quantize_rows_fp8.
+ * Products run on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; twice the bf16 MFMA rate), accumulate in
+ * float32, and the epilogue applies a_scale[m] * w_scale[n] before the bias and the fused activation / gate /
+ * residual, which are the same as fluxhip_gemm_bf16's.  Outputs stay bf16. */
+
+/* x bf16 [rows][ld] (first K columns) -> out e4m3fn [rows][K], scale float32 [rows]:
+ * scale[r] = max|x[r,:]| / 448 (1 if the row is zero), out = round_to_nearest_even(x / scale).  K % 16 == 0. */
+int fluxhip_quantize_rows_fp8(const void* x, void* out, void* scale, int64_t rows, int K, int64_t ld, void* stream);
+/* float32 [rows][K] source (weights kept in a wider master dtype), same output. */
+int fluxhip_quantize_rows_fp8_f32(const void* x, void* out, void* scale, int64_t rows, int K, int64_t ld, void* stream);
+
+typedef struct fluxhip_fp8_scales {
+  const void* a_scale[2];   /* float32 [nbatch][M] per group: one per row of A                     */
+  const void* w_scale[2];   /* float32 [N] per group: one per row of W (output channel)            */
+  int64_t a_scale_bstride;  /* elements between batches of a_scale                                  */
+} fluxhip_fp8_scales;
+/* `d` as for fluxhip_gemm_bf16 with A and W pointing at e4m3fn bytes (lda, strides and K in ELEMENTS; K % 128 == 0,
+ * lda % 16 == 0); bias / C / res / gate / C2 stay bf16. */
+int fluxhip_gemm_fp8(const fluxhip_gemm_desc* d, const fluxhip_fp8_scales* sc, void* stream);
+int fluxhip_gemm_fp8_tile_cfg(const fluxhip_gemm_desc* d);
+
 /* ---- text encoders (flux/t5.py, flux/clip.py) ------------------------- */
 
 /* head_dim-64 attention with either an additive per-head bias [H][Tq][Tk] bf16 (T5: relative position

@@ -1,0 +1,146 @@
+"""fp8 path (BASELINE.json configs[4]; the reference's `--quantize`, txt2image.py:26-28,79-82): e4m3fn weights with
+per-output-channel scales, per-token e4m3fn activations, fp8 matrix cores, bf16 outputs.
+
+Tolerances:
+  * the row quantiser is BIT-EXACT against torch's float8_e4m3fn round-to-nearest-even conversion of x / scale;
+  * fluxhip_gemm_fp8 vs a float64 product of the DEQUANTISED operands: rel-L2 <= 4e-3 (fp32 accumulation, bf16 output
+    rounding — the quantisation itself is outside this comparison, so the kernel is checked exactly);
+  * a whole tiny Flux forward in fp8 vs the fp32 oracle evaluated with the DE-QUANTISED weights: rel-L2 <= 6e-2 — the
+    remaining difference is the per-token e4m3 rounding of the activations (3 mantissa bits, ~2^-4 relative per
+    element, averaging down over each 256..1280-term dot product) accumulated over the blocks.
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import flux_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(*shape, scale=1.0, seed=0, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(dev)
+
+
+def deq(q, s):
+    return q.cpu().view(torch.float8_e4m3fn).float() * s.cpu()[:, None]
+
+
+@pytest.mark.parametrize("rows,K,f32", [(37, 256, False), (5, 15360, False), (64, 3072, True)])
+def test_quantize_rows_bit_exact(dev, rows, K, f32):
+    from flux_generator_amd import ops
+    x = rnd(rows, K, seed=1, scale=3.0)
+    x[0] = 0                                                     # an all-zero row keeps scale 1
+    x[1, 5] = 1000.0                                             # an outlier sets its row's scale
+    if f32:
+        x = x.float() * 1.2345
+    q, s = ops.quantize_rows_fp8(x)
+    xf = x.float().cpu()
+    amax = xf.abs().amax(dim=1)
+    want_s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    assert torch.equal(s.cpu(), want_s)
+    want_q = (xf * (1.0 / want_s)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q.cpu(), want_q)
+    assert int(q[0].max()) == 0 and float(deq(q, s)[1, 5]) == pytest.approx(1000.0 * (1.2345 if f32 else 1.0), rel=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,cfg", [(300, 512, 256, 0), (1280, 3072, 3072, 0), (1280, 9216, 3072, 0), (100, 64, 128, 0),
+                                        (512, 768, 1280, 55), (512, 768, 1280, 53), (512, 768, 1280, 1), (512, 768, 1280, 2),
+                                        (512, 768, 1280, 3), (512, 768, 1280, 4), (512, 640, 1280, 54), (512, 384, 1280, 52),
+                                        (4352, 3072, 15360, 0)])
+def test_gemm_fp8(dev, M, N, K, cfg):
+    from flux_generator_amd import ops
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, wsc = ops.quantize_rows_fp8(w)
+    ref = deq(xq, xs).double() @ deq(wq, wsc).double().T + b.double().cpu()
+    got = ops.linear_fp8(xq, xs, wq, wsc, b, tile_cfg=cfg)
+    e = rel_l2(got, ref.float())
+    eq = rel_l2(ref.float(), x.float().cpu() @ w.float().cpu().T + b.float().cpu())
+    print(f"gemm_fp8 {M}x{N}x{K} cfg {cfg}: kernel rel-L2 {e:.2e}; e4m3 quantisation of both operands costs {eq:.2e}")
+    assert e < 4e-3
+    # fused epilogues share the bf16 path's code: gated residual + GELU
+    res, gate = rnd(M, N, seed=4), rnd(N, seed=5)
+    got = ops.linear_fp8(xq, xs, wq, wsc, b, epi=ops.EPI_GATE_RES, res=res, gate=gate, tile_cfg=cfg)
+    want = res.float().cpu() + gate.float().cpu() * ref.float().to(BF).float()
+    assert rel_l2(got, want) < 4e-3
+    got = ops.linear_fp8(xq, xs, wq, wsc, b, epi=ops.EPI_GELU_TANH, tile_cfg=cfg)
+    assert rel_l2(got, O.gelu_tanh(ref.float())) < 6e-3
+    if cfg in (49, 50, 51):
+        return
+
+
+def test_gemm_fp8_rejects_uninstantiated_tiles(dev):
+    """Tiles without an fp8 kernel (the 256-wide ping-pong tiles that would spill) are refused, not run."""
+    from flux_generator_amd import ops
+    x, w = rnd(256, 256, seed=1), rnd(256, 256, seed=2)
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, wsc = ops.quantize_rows_fp8(w)
+    with pytest.raises(ops.FluxHipError):
+        ops.linear_fp8(xq, xs, wq, wsc, None, tile_cfg=49)
+
+
+def _tiny(dev, guidance=False):
+    from flux_generator_amd.flux.model import Flux, FluxParams
+    kw = dict(in_channels=64, vec_in_dim=64, context_in_dim=128, hidden_size=256, mlp_ratio=4.0, num_heads=2, depth=2,
+              depth_single_blocks=3, axes_dim=[16, 56, 56], theta=10_000, qkv_bias=True, guidance_embed=guidance)
+    OP = O.FluxParams(**kw)
+    W = {k: v.to(BF).float() for k, v in O.init_weights(O.flux_weight_shapes(OP), seed=0, norm_jitter=0.2).items()}
+    return OP, W, Flux(FluxParams(**kw), device=dev).load_weights(W)
+
+
+@pytest.mark.parametrize("B,S,hw", [(1, 64, (16, 16)), (2, 40, (12, 20))])
+def test_flux_forward_fp8(dev, B, S, hw):
+    OP, W, model = _tiny(dev)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(B, *hw, 16, generator=g).to(BF)
+    img, ids = O.prepare_latent_images(z)
+    txt = (torch.randn(B, S, 128, generator=g) * 0.5).to(BF)
+    tids = torch.zeros(B, S, 3, dtype=torch.int32)
+    vec = torch.randn(B, 64, generator=g).to(BF)
+    t = torch.full((B,), 0.75, dtype=BF)
+    args = [a.to(dev) for a in (img, ids, txt, tids, t, vec)]
+    bf16_out = model(*args)
+    model.enable_fp8()
+    assert model.fp8 and len(model._w8) == 2 * 2 * 4 + 3 * 2
+    got = model(*args)
+    again = model(*args)
+    assert torch.equal(got, again)
+    Wd = dict(W)                                                  # oracle weights = the de-quantised e4m3 weights
+    for name, (q, s) in model._w8.items():
+        Wd[f"{name}.weight"] = deq(q, s)
+        assert rel_l2(Wd[f"{name}.weight"], W[f"{name}.weight"]) < 4e-2       # e4m3: 3 mantissa bits
+    ref = O.flux_forward(OP, Wd, img.float(), ids, txt.float(), tids, t, vec.float())
+    e, e16 = rel_l2(got, ref), rel_l2(got, bf16_out.float().cpu())
+    print(f"fp8 tiny forward: rel-L2 vs oracle(dequantised weights) {e:.2e}; vs the bf16 HIP forward {e16:.2e}")
+    assert e < 6e-2
+    model.enable_fp8(False)
+    assert torch.equal(model(*args), bf16_out)                    # switching back restores the bf16 plan exactly
+
+
+def test_full_width_block_fp8(dev):
+    """One double + one single block at Flux's real width (K = 3072 / 12288 / 15360) in fp8 vs the oracle on the
+    de-quantised weights."""
+    from flux_generator_amd.flux.model import Flux, FluxParams
+    kw = dict(in_channels=64, vec_in_dim=768, context_in_dim=4096, hidden_size=3072, mlp_ratio=4.0, num_heads=24, depth=1,
+              depth_single_blocks=1, axes_dim=[16, 56, 56], theta=10_000, qkv_bias=True, guidance_embed=False)
+    OP = O.FluxParams(**kw)
+    W = {k: v.to(BF).float() for k, v in O.init_weights(O.flux_weight_shapes(OP), seed=5, norm_jitter=0.2).items()}
+    model = Flux(FluxParams(**kw), device=dev).load_weights(W).enable_fp8()
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(1, 32, 32, 16, generator=g).to(BF)
+    img, ids = O.prepare_latent_images(z)
+    txt = (torch.randn(1, 64, 4096, generator=g) * 0.5).to(BF)
+    tids = torch.zeros(1, 64, 3, dtype=torch.int32)
+    vec = torch.randn(1, 768, generator=g).to(BF)
+    t = torch.full((1,), 0.5, dtype=BF)
+    Wd = dict(W)
+    for name, (q, s) in model._w8.items():
+        Wd[f"{name}.weight"] = deq(q, s)
+    ref = O.flux_forward(OP, Wd, img.float(), ids, txt.float(), tids, t, vec.float())
+    got = model(img.to(dev), ids.to(dev), txt.to(dev), tids.to(dev), t.to(dev), vec.to(dev))
+    e = rel_l2(got, ref)
+    print(f"fp8 full-width blocks: rel-L2 {e:.2e}")
+    assert e < 4e-2

@@ -58,8 +58,6 @@ def main(argv=None):
     args.steps = args.steps or (50 if args.model == "dev" else 2)
     if not torch.cuda.is_available():
         sys.exit("txt2image.py needs an MI355X (HIP) device: the denoise/decode path has no CPU fallback")
-    if args.quantize:
-        print("Note: --quantize (MLX 4/8-bit nn.quantize) has no effect here; weights stay bf16")
 
     # `torchrun --nproc-per-node N txt2image.py ...`: one process per GPU, the --n-images batch is sharded by image
     # (rank 0 encodes the prompt and broadcasts txt / vec over RCCL, rank 0 saves the gathered images)
@@ -78,6 +76,10 @@ def main(argv=None):
     if args.adapter:
         n = flux.load_adapter(args.adapter, fuse=args.fuse_adapter)
         print(f"Applied LoRA adapter {args.adapter} to {n} layers", file=sys.stderr)
+    if args.quantize:
+        # the reference's nn.quantize (txt2image.py:79-82) re-designed for CDNA4: e4m3 weights (per output channel) and
+        # per-token e4m3 activations of the transformer blocks' Linears on the fp8 matrix cores
+        flux.flow.enable_fp8()
     if args.preload_models:
         flux.ensure_models_are_loaded()
 
