@@ -46,7 +46,11 @@ struct AttnParams {
 // (max, sum, O) states are merged through LDS at the end.  At batch 1 the Flux grid is 240 workgroups for
 // 256 CUs: with KS = 1 that is one wave per SIMD, and the MFMA pipe idles through every softmax phase; with
 // KS = 2 each SIMD holds two waves in different phases.
-template <int HD, int NW, int MODE, int KS = 1>
+// VP = 1: the keys of V^T are stored permuted inside every aligned group of 16 as [0-3, 8-11, 4-7, 12-15] (written that
+// way by fluxhip_qk_norm_rope_bf16): the 8 keys a lane feeds to one PV MFMA - (0-3, 8-11) for lanes 0-31, (4-7, 12-15)
+// for lanes 32-63 - are then ONE 16-byte chunk, i.e. one conflict-free ds_read_b128 per fragment instead of two
+// ds_read_b64 (whose 8-byte accesses were 2-way bank conflicted: 30 % of the kernel's LDS cycles in the round-1 PMC).
+template <int HD, int NW, int MODE, int KS = 1, int VP = 0>
 __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(const AttnParams p) {
   constexpr int RB = HD * 2;                  // bytes per K row
   constexpr int CPR = RB / 16;                // 16-B chunks per K row
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
   const int k_rowoff = ql * RB;
   const int k_sw = (HD == 128) ? (ql & 15) : ((ql >> 1) & 7);
   // V^T (A operand): row d = db*32 + ql ; bytes: ((kb*4 + j*2 + {0,1}) ^ ((d>>1)&7))*16 + hi*8
-  const int v_rowoff = ql * 128 + hi * 8;
+  const int v_rowoff = ql * 128 + (VP ? 0 : hi * 8);
   const int v_sw = (ql >> 1) & 7;
   // LDS byte offsets of the fragments inside a stage (the swizzle is an XOR, so one register per chunk)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
 #pragma unroll
   for (int ds = 0; ds < NDS; ++ds) koff[ds] = k_rowoff + (((ds * 2 + hi) ^ k_sw) << 4);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) voff[c] = KT_BYTES + v_rowoff + ((c ^ v_sw) << 4);
+  for (int c = 0; c < 8; ++c) voff[c] = KT_BYTES + v_rowoff + (((VP ? (c | hi) : c) ^ v_sw) << 4);   // VP: only even c are used
 
   int ntiles = (Tk + KV - 1) / KV;
   // causal: keys beyond the workgroup's last query row are all masked (block-uniform trip count:
@@ -211,8 +215,12 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(vf[j][db].h[0]) : "v"(sbase + voff[kb * 4 + j * 2]), "n"(db * 32 * 128) : "memory");
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(vf[j][db].h[1]) : "v"(sbase + voff[kb * 4 + j * 2 + 1]), "n"(db * 32 * 128) : "memory");
+          if constexpr (VP) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[j][db].v) : "v"(sbase + voff[kb * 4 + j * 2]), "n"(db * 32 * 128) : "memory");
+          } else {
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(vf[j][db].h[0]) : "v"(sbase + voff[kb * 4 + j * 2]), "n"(db * 32 * 128) : "memory");
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(vf[j][db].h[1]) : "v"(sbase + voff[kb * 4 + j * 2 + 1]), "n"(db * 32 * 128) : "memory");
+          }
         }
     };
     read_v(vf0, 0);
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = pair32_max(mx);
     const float m_new = fmaxf(m_run, mx);
     // Lazy rescale: softmax is shift-invariant, so the running reference only has to keep exp2 in range.
     // It moves when some query's maximum grew by more than 8 in the log2 domain (P <= 2^8 otherwise);
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
   }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l -----------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = pair32_sum(l_run);
   const float inv = 1.f / l_tot;
   const int q = q0 + ql;
   if (q < Tq) {
@@ -355,15 +363,13 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
   }
 }
 
-bool g_attr_done[2][3] = {};
 
-template <int HD, int MODE, int KS = 1>
+template <int HD, int MODE, int KS = 1, int VP = 0>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
   constexpr int NW = 4;
   constexpr int lds = 2 * KS * (KV * HD * 2 + HD * KV * 2);
-  auto fn = attn_kernel<HD, NW, MODE, KS>;
-  static bool split_done = false;
-  bool& done = KS == 2 ? split_done : g_attr_done[HD == 128 ? 0 : 1][MODE];
+  auto fn = attn_kernel<HD, NW, MODE, KS, VP>;
+  static bool done = false;            // one flag per template instantiation
   if (!done) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return FLUXHIP_ELAUNCH;
@@ -390,9 +396,9 @@ extern "C" int fluxhip_attention_d128_bf16(const void* Q, const void* K, const v
   p.scale_log2 = scale * 1.4426950408889634f;
   // fewer workgroups than two per CU: split the KV tiles over a second wave set instead (see attn_kernel)
   static const int variant = [] { const char* e = getenv("FLUXHIP_ATTN"); return e ? atoi(e) : 0; }();   // tuning knob (tools/attn_bench.py)
-  if (variant == 2) return launch_attn<128, 0>(p, B, (hipStream_t)stream);
-  if ((long long)B * H * p.nqb < 384 && T > 2 * KV) return launch_attn<128, 0, 2>(p, B, (hipStream_t)stream);
-  return launch_attn<128, 0>(p, B, (hipStream_t)stream);
+  if (variant == 2) return launch_attn<128, 0, 1, 1>(p, B, (hipStream_t)stream);
+  if ((long long)B * H * p.nqb < 384 && T > 2 * KV) return launch_attn<128, 0, 2, 1>(p, B, (hipStream_t)stream);
+  return launch_attn<128, 0, 1, 1>(p, B, (hipStream_t)stream);
 }
 
 extern "C" int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,

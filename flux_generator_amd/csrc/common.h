@@ -62,6 +62,19 @@ DEVINL float wave_max(float v) {
   return v;
 }
 
+// Exchange between the two 32-lane halves of a wave without the LDS crossbar (v_permlane32_swap_b32, gfx950):
+// with both operands = v the result pair is (v of lane l&31, v of lane (l&31)+32) in EVERY lane, so the
+// max / sum over the lane pair (l, l^32) needs no select.  (__shfl_xor(v, 32) is a ds_bpermute: LDS latency plus an
+// lgkmcnt wait that also drains every outstanding ds_read of the wave.)
+DEVINL float pair32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+DEVINL float pair32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // 16-byte async copy global -> LDS. LDS destination = wave-uniform base + lane*16.
 DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(

@@ -158,6 +158,7 @@ const Cand kF8Cands[] = {
 
 // Split-K workspace (fluxhip_set_workspace): [kSkMaxTiles] int32 hand-off counters, then fp32 partial tiles.
 constexpr int kSkMaxTiles = 16384;
+constexpr long long kSkFlagBytes = (long long)kSkMaxTiles * 4;
 char* g_ws = nullptr;
 long long g_ws_bytes = 0;
 constexpr float kHopUs = 20.0f, kHopNextUs = 8.0f;   // measured cost of the first / each further hand-off of a chain
@@ -177,7 +178,7 @@ int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbat
     for (int S = 1; S <= 4; ++S) {
       if (S > 1) {   // only under-filled grids with a long K loop, and only if the workspace can hold the partials
         if (c.bpc != 1 || tiles * S > slots || nkt / S < 16 || tiles > kSkMaxTiles) break;
-        if ((long long)kSkMaxTiles * 4 + tiles * t.bm * t.bn * 4LL > g_ws_bytes) break;
+        if (kSkFlagBytes + tiles * t.bm * t.bn * 4LL > g_ws_bytes) break;
       }
       const long long rounds = (tiles * S + slots - 1) / slots;
       const float hop = S > 1 ? kHopUs + (float)(S - 2) * kHopNextUs : 0.f;
@@ -236,10 +237,10 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
   if (splits > 1) {
     const long long tiles = (long long)tm_total * p.tiles_n;
     if (splits > (f8 ? p.K / 128 : (x3 ? 3 : 1) * (p.K / 64)) || tiles > kSkMaxTiles ||
-        (long long)kSkMaxTiles * 4 + tiles * c.bm * c.bn * 4LL > g_ws_bytes)
+        kSkFlagBytes + tiles * c.bm * c.bn * 4LL > g_ws_bytes)
       return FLUXHIP_EINVAL;                        // no (or too small a) split-K workspace
     p.sk_flag = (int*)g_ws;
-    p.sk_part = (float*)(g_ws + (long long)kSkMaxTiles * 4);
+    p.sk_part = (float*)(g_ws + kSkFlagBytes);
   }
   dim3 grid(tm_total * p.tiles_n * splits), block(c.threads);
   hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);
@@ -365,7 +366,7 @@ extern "C" int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d) {
 }
 
 extern "C" int fluxhip_set_workspace(void* ws, int64_t bytes) {
-  if (ws && (bytes < (int64_t)kSkMaxTiles * 4 || ((uintptr_t)ws & 255))) return FLUXHIP_EINVAL;
+  if (ws && (bytes < (int64_t)kSkFlagBytes || ((uintptr_t)ws & 255))) return FLUXHIP_EINVAL;
   g_ws = (char*)ws;
   g_ws_bytes = ws ? bytes : 0;
   return FLUXHIP_OK;

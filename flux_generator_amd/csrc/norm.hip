@@ -171,9 +171,15 @@ __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(
       int idx = tid + i * 256;
       int d = idx >> 3, c = idx & 7;
       uint32_t o[4];
+      // key permutation inside every aligned group of 16 keys: stored order [0-3, 8-11, 4-7, 12-15] (what one PV
+      // MFMA fragment of the attention kernel consumes is then one 16-byte chunk; see attn_kernel, VP)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        o[e] = (uint32_t)vt_tile[c * 8 + 2 * e][d] | ((uint32_t)vt_tile[c * 8 + 2 * e + 1][d] << 16);
+      for (int e = 0; e < 4; ++e) {
+        const int pp = (c & 1) * 8 + 2 * e;                      // stored position inside the 16-key group (even)
+        const int pg = pp >> 2, g = ((pg & 1) << 1) | (pg >> 1);  // 4-key sub-group stored there
+        const int tk = (c >> 1) * 16 + g * 4 + (pp & 3);          // token (inside the 64-token tile) of that position
+        o[e] = (uint32_t)vt_tile[tk][d] | ((uint32_t)vt_tile[tk + 1][d] << 16);
+      }
       bf16_t* dst = Vt + (((long long)b * H + h) * 128 + d) * Tpad + t0 + c * 8;
       *(u32x4*)dst = u32x4{o[0], o[1], o[2], o[3]};
     }

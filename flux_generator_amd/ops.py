@@ -113,6 +113,16 @@ def qk_norm_rope(qkv: torch.Tensor, ld: int, B: int, T: int, S: int, H: int, qw_
                                                   _stream()), "fluxhip_qk_norm_rope_bf16")
 
 
+def vt_key_permutation(tpad: int, device=None) -> torch.Tensor:
+    """Index map of the key-permuted V^T layout (include/fluxhip.h, fluxhip_qk_norm_rope_bf16): stored column p holds
+    key perm[p]; inside every aligned group of 16 keys the stored order is [0-3, 8-11, 4-7, 12-15].  For callers that
+    build V^T themselves (tests, tools): vt_stored = vt_natural[..., perm]."""
+    p = torch.arange(tpad, device=device)
+    pg = (p & 15) >> 2
+    g = ((pg & 1) << 1) | (pg >> 1)
+    return (p & ~15) + g * 4 + (p & 3)
+
+
 def attention_d128(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, O, ldo: int, B: int, H: int, T: int, Tpad: int,
                    scale: float) -> None:
     _check(_lib.load().fluxhip_attention_d128_bf16(_p(Q), _p(K), _p(Vt), _p(O) if isinstance(O, torch.Tensor) else O,

@@ -133,7 +133,9 @@ int fluxhip_ln_modulate_bf16(const void* x, void* out, int B, int Tr, int D, int
  * qkv: bf16 [B*T][ld], q at col 0, k at col H*128, v at col 2*H*128 (head-major inside each).
  * rope: bf16 [T][64][2] = (cos, sin) per rotation pair (already rounded to bf16 like the
  * reference's pe.astype(bf16), flux/model.py:124); batch b reads rope + b*rope_bstride (0 = shared).
- * Outputs: Q,K bf16 [B][H][T][128]; Vt bf16 [B][H][128][Tpad] with zero padding for t >= T. */
+ * Outputs: Q,K bf16 [B][H][T][128]; Vt bf16 [B][H][128][Tpad] with zero padding for t >= T, keys stored PERMUTED inside
+ * every aligned group of 16 as [0-3, 8-11, 4-7, 12-15] — the order in which fluxhip_attention_d128_bf16's PV MFMA
+ * consumes them (one 16-byte LDS read per fragment). */
 int fluxhip_qk_norm_rope_bf16(const void* qkv, int ld, int B, int T, int S, int H,
                               const void* qw_txt, const void* kw_txt, const void* qw_img,
                               const void* kw_img, const void* rope, int64_t rope_bstride, void* Q,
@@ -141,7 +143,8 @@ int fluxhip_qk_norm_rope_bf16(const void* qkv, int ld, int B, int T, int S, int 
 
 /* Joint (txt+img) non-causal attention, head_dim 128: O[b,t,h*128:(h+1)*128] =
  * softmax(scale * Q K^T) V.  Replaces mx.fast.scaled_dot_product_attention + the
- * transpose/reshape at flux/layers.py:36-43.  O is token-major with row stride ldo. */
+ * transpose/reshape at flux/layers.py:36-43.  O is token-major with row stride ldo.  Vt in the key-permuted layout
+ * fluxhip_qk_norm_rope_bf16 writes (see there). */
 int fluxhip_attention_d128_bf16(const void* Q, const void* K, const void* Vt, void* O, int ldo,
                                 int B, int H, int T, int Tpad, float scale, void* stream);
 

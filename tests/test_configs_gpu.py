@@ -38,6 +38,7 @@ def test_attention_long(dev, B, H, T, heads):
     q, k, v = rnd(B, H, T, 128, seed=1), rnd(B, H, T, 128, seed=2), rnd(B, H, T, 128, seed=3)
     vt = torch.zeros(B, H, 128, Tpad, dtype=BF, device=dev)
     vt[..., :T] = v.transpose(-1, -2)
+    vt = vt[..., ops.vt_key_permutation(Tpad, dev)].contiguous()
     o = torch.empty(B, T, H * 128, dtype=BF, device=dev)
     ops.attention_d128(q, k, vt, o, H * 128, B, H, T, Tpad, 128 ** -0.5)
     o2 = torch.empty_like(o)
@@ -176,7 +177,7 @@ def test_c1_txt2image_cli_on_gpu(dev, tmp_path, monkeypatch):
         # same seed -> same image; --save-raw writes name.{i}.suffix
         out2 = tmp_path / "raw.png"
         txt2image.main(["a photo of an astronaut riding a horse", "--model", "schnell", "--n-images", "2", "--image-size",
-                        "256x256", "--steps", "2", "--seed", "7", "--output", str(out2), "--save-raw"])
+                        "256x256", "--steps", "2", "--seed", "7", "--output", str(out2), "--save-raw", "-q"])   # -q: fp8 blocks
     a, b = np.asarray(Image.open(tmp_path / "raw.0.png")), np.asarray(Image.open(tmp_path / "raw.1.png"))
     assert a.shape == (256, 256, 3) and not np.array_equal(a, b)
 

@@ -98,6 +98,27 @@ def test_gemm_split_k(dev, cfg, S):
     assert rel_l2(outs[0], plain.float().cpu()) < 1e-2
 
 
+@pytest.mark.parametrize("cfg,S", [(51, 3), (49, 4), (46, 2), (55, 2)])
+def test_gemm_split_k_no_stale_partials(dev, cfg, S):
+    """The partial-tile slots are reused by every launch: alternating two different problems through the same
+    workspace must give each its own result every time (a reducer that read a stale partial of the previous launch from
+    a cache would reproduce the OTHER problem's contribution), also with other traffic in between."""
+    from flux_generator_amd import ops
+    M, N, K = 1280, 3072, 4096
+    xs = [rnd(M, K, seed=s) for s in (1, 2)]
+    w = rnd(N, K, seed=3, scale=K ** -0.5)
+    first = [ops.linear(x, w, None, tile_cfg=cfg | (S << 8)).clone() for x in xs]
+    assert not torch.equal(first[0], first[1])
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    for it in range(6):
+        i = it & 1
+        if it % 3 == 2:
+            junk.random_(0, 255)                # churn L2 / MALL between launches
+        y = ops.linear(xs[i], w, None, tile_cfg=cfg | (S << 8))
+        assert torch.equal(y, first[i]), f"iteration {it}"
+    assert rel_l2(first[0], O.linear(xs[0].float().cpu(), w.float().cpu(), None)) < TOL
+
+
 def test_gemm_split_k_oversubscribed(dev):
     """More split-K blocks than the chip can hold at once: consumers only ever wait for lower block ids."""
     from flux_generator_amd import ops
@@ -239,8 +260,13 @@ def test_qk_norm_rope_vt(dev, T, S):
     qr = O.apply_rope(norm(q, ws[0], ws[2]), pe)
     kr = O.apply_rope(norm(k, ws[1], ws[3]), pe)
     assert rel_l2(Q, qr) < TOL and rel_l2(K, kr) < TOL
-    assert torch.equal(Vt[..., :T].float().cpu(), v.transpose(-1, -2))        # pure data movement: exact
-    assert torch.count_nonzero(Vt[..., T:]) == 0                                # zero padding
+    # V^T: pure data movement (exact), zero padded to Tpad keys, keys permuted inside every group of 16 as
+    # [0-3, 8-11, 4-7, 12-15] (the attention kernel's PV fragment order, include/fluxhip.h)
+    want = torch.zeros(B, H, 128, Tpad)
+    want[..., :T] = v.transpose(-1, -2)
+    perm = ops.vt_key_permutation(Tpad)
+    assert perm[:16].tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15] and int(perm[16]) == 16
+    assert torch.equal(Vt.float().cpu(), want[..., perm])
     # rope table itself (cos, sin) vs the oracle's rotation matrices, both rounded to bf16
     assert rel_l2(rope[..., 0], pe[:, 0, :, :, 0, 0]) < 1e-3 and rel_l2(rope[..., 1], pe[:, 0, :, :, 1, 0]) < 1e-3
 
@@ -253,6 +279,7 @@ def test_attention(dev, B, H, T):
     q, k, v = rnd(B, H, T, 128, seed=1), rnd(B, H, T, 128, seed=2), rnd(B, H, T, 128, seed=3)
     vt = torch.zeros(B, H, 128, Tpad, dtype=BF, device=dev)
     vt[..., :T] = v.transpose(-1, -2)
+    vt = vt[..., ops.vt_key_permutation(Tpad, dev)].contiguous()           # the layout fluxhip_qk_norm_rope_bf16 writes
     o = torch.empty(B, T, H * 128, dtype=BF, device=dev)
     ops.attention_d128(q, k, vt, o, H * 128, B, H, T, Tpad, 128 ** -0.5)
     ref = O.sdpa(q.float().cpu(), k.float().cpu(), v.float().cpu(), 128 ** -0.5).transpose(1, 2).reshape(B, T, -1)
@@ -269,7 +296,7 @@ def test_attention_forced_rescale(dev):
     q, k, v = rnd(B, H, T, 128, seed=1), rnd(B, H, T, 128, seed=2, scale=0.1), rnd(B, H, T, 128, seed=3)
     k[0, 0, 200] = q[0, 0, 17] * 2.0          # query 17 meets its spike in the 4th key tile
     k[0, 0, 70] = q[0, 0, 140] * 1.5
-    vt = v.transpose(-1, -2).contiguous()
+    vt = v.transpose(-1, -2)[..., ops.vt_key_permutation(T, dev)].contiguous()
     o = torch.empty(B, T, 128, dtype=BF, device=dev)
     ops.attention_d128(q, k, vt, o, 128, B, H, T, T, 128 ** -0.5)
     ref = O.sdpa(q.float().cpu(), k.float().cpu(), v.float().cpu(), 128 ** -0.5).transpose(1, 2).reshape(B, T, -1)

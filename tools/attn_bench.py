@@ -15,6 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         k = torch.randn(B, H, T, 128, device="cuda").to(torch.bfloat16)
         v = torch.randn(B, H, T, 128, device="cuda").to(torch.bfloat16)
         vt = torch.zeros(B, H, 128, Tp, dtype=torch.bfloat16, device="cuda"); vt[..., :T] = v.transpose(-1, -2)
+        vt = vt[..., ops.vt_key_permutation(Tp, "cuda")].contiguous()      # key-permuted V^T layout (include/fluxhip.h)
         o = torch.empty(B, T, H * 128, dtype=torch.bfloat16, device="cuda")
         for _ in range(3):
             ops.attention_d128(q, k, vt, o, H * 128, B, H, T, Tp, 128 ** -0.5)

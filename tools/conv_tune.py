@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time the VAE decoder's conv shapes per forced tile configuration (FLUXHIP_CONV_CFG is read once per
-process, so this script re-executes itself per configuration)."""
+process, so this script re-executes itself per configuration).  TUNE_X3=1: the fp32-faithful split-bf16 conv
+(FLUXHIP_CONV_X3_CFG; reported TFLOP/s count the 3 MFMA passes)."""
 import os, sys, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [(64, 512, 512, False), (64, 512, 512, True), (128, 512, 512, False), (128, 512, 512, True), (256, 512, 256, False),
@@ -11,20 +12,27 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     torch.manual_seed(0)
     out = {}
     for (H, Cin, Cout, ups) in SHAPES:
-        x = torch.randn(1, H, H, Cin, device="cuda").to(torch.bfloat16)
-        w = (torch.randn(Cout, 3, 3, Cin, device="cuda") * (9 * Cin) ** -0.5).to(torch.bfloat16)
-        b = torch.randn(Cout, device="cuda").to(torch.bfloat16)
+        X3 = bool(os.environ.get("TUNE_X3"))
+        x = torch.randn(1, H, H, Cin, device="cuda")
+        w = torch.randn(Cout, 3, 3, Cin, device="cuda") * (9 * Cin) ** -0.5
+        b = torch.randn(Cout, device="cuda")
+        if X3:
+            x, w = ops.split_f32(x), ops.split_f32(w)
+            conv = ops.conv2d_x3
+        else:
+            x, w, b = x.to(torch.bfloat16), w.to(torch.bfloat16), b.to(torch.bfloat16)
+            conv = ops.conv2d
         try:
             for _ in range(3):
-                y = ops.conv2d(x, w, b, ups=ups)
+                y = conv(x, w, b, ups=ups)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                ops.conv2d(x, w, b, ups=ups, out=y)
+                conv(x, w, b, ups=ups, out=y)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 10
             Ho = H * 2 if ups else H
-            out[f"{H}{'u' if ups else ''}:{Cin}->{Cout}"] = (round(2.0 * Ho * Ho * Cout * Cin * 9 / ms / 1e9), float(y.float().abs().mean()))
+            out[f"{H}{'u' if ups else ''}:{Cin}->{Cout}"] = (round((3 if X3 else 1) * 2.0 * Ho * Ho * Cout * Cin * 9 / ms / 1e9), float(y.float().abs().mean()))
         except Exception as ex:
             out[f"{H}:{Cin}->{Cout}"] = ("ERR", 0)
     print("RESULT " + json.dumps(out))
@@ -32,7 +40,7 @@ else:
     cfgs = sys.argv[1:] or ["0"]
     rows = {}
     for c in cfgs:
-        env = dict(os.environ); env["FLUXHIP_CONV_CFG"] = c
+        env = dict(os.environ); env["FLUXHIP_CONV_CFG"] = c; env["FLUXHIP_CONV_X3_CFG"] = c
         r = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
         rows[c] = json.loads(line[0][7:]) if line else {"fail": (r.stderr[-300:], 0)}

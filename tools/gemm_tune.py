@@ -79,6 +79,6 @@ for name, (m, n, k, epi) in shapes.items():
         torch.cuda.synchronize()
         row["blaslt"] = round(2.0 * m * n * k / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12, 1)
     res[name] = row
-    best = max((v, c) for c, v in row.items() if isinstance(v, float) and c != "blaslt")
+    best = max([(v, c) for c, v in row.items() if isinstance(v, float) and c != "blaslt"] or [(0.0, 0)])
     print(f"{name:12s} M={m} N={n} K={k}: " + " ".join(f"c{c if isinstance(c, str) or c < 256 else str(c & 255) + 's' + str(c >> 8)}={v}" for c, v in row.items()) + f"  BEST c{best[1]}={best[0]}", flush=True)
 print(json.dumps(res))
