@@ -122,9 +122,15 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # BENCH_FORCE_DIST=1: create the RCCL process group even at world size 1, so a single-GPU box runs exactly the
+    # broadcast / barrier / max-reduce / gather code an 8-GPU launch runs
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -165,7 +171,7 @@ def main() -> None:
         return pipe.decode(x, (lat, lat))
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -183,7 +189,7 @@ def main() -> None:
         img = one_pass()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -248,7 +254,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"{args.model.replace('flux-', 'Flux-')} {args.image_size}x{args.image_size} {args.denoise_steps}-step, "
                                    f"batch {B}/GPU, random-init weights, synthetic x_T/txt/vec resident in HBM; "
-                                   "per step: 2 x (Flux forward + Euler) + VAE decode",
+                                   f"per step: {args.denoise_steps} x (Flux forward + Euler) + VAE decode (fp32-faithful)",
                        "global_batch": B * world, "parallelism": f"dp{world} (batch sharded by image; txt/vec broadcast from rank 0 before and uint8 gather after the timed region, no collective inside)",
                        "denoise_step_ms": step_ms, "vae_decode_ms": decode_ms["fp32"],
                        "vae_precision": "fp32-faithful, like the reference's fp32 AE (bf16 hi/lo planes, 3 MFMA passes, fp32 accumulate / norms / softmax)",
@@ -259,9 +265,24 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sample(L + S, torch.get_num_threads())
-        print(json.dumps(out))
-    if world > 1:
+    # RCCL prints its version banner through C stdio (flushed at exit when stdout is a pipe).  Every rank flushes it
+    # now, then a barrier, then rank 0 prints: the JSON line is the LAST line of the job's output.
+    def flush_c_stdio():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+
+    flush_c_stdio()
+    if use_dist:
         import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+    if rank == 0:
+        flush_c_stdio()
+        print(json.dumps(out), flush=True)
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -32,10 +32,13 @@ for _ in range(steps):
     img = one()
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
-e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+pipe.decode(x_T, precision="bf16")
 e0.record(); x = pipe._denoising_step(x_T, t, tp, cond, 0.0, tt); e1.record(); pipe.decode(x); e2.record()
+pipe.decode(x, precision="bf16"); e3.record()
 torch.cuda.synchronize()
 unet_flop = 1.59e12 * B
 print(json.dumps({"workload": f"sdxl-turbo 512x512 1-step batch {B}", "images_per_sec": B * steps / el,
                   "unet_step_ms": e0.elapsed_time(e1), "vae_decode_ms": e1.elapsed_time(e2),
+                  "vae_precision": "fp32-faithful (the reference's float32 VAE)", "vae_decode_ms_bf16_storage_optin": e2.elapsed_time(e3),
                   "unet_tflops": unet_flop / (e0.elapsed_time(e1) * 1e-3) / 1e12, "finite": bool(torch.isfinite(img).all())}))
