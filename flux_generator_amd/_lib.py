@@ -123,6 +123,13 @@ def load() -> C.CDLL:
             f"libfluxhip.so not found at {LIB_PATH}. Build it with "
             f"`python -c 'import __graft_entry__ as g; g.build()'` or flux_generator_amd/csrc/build.sh. "
             "There is no CPU / PyTorch fallback for the denoise path.")
+    # torch first: its wheel bundles its own libamdhip64, and every launch of this library must go through the SAME HIP
+    # runtime that owns torch's streams and allocations.  dlopen'ing libfluxhip.so before torch would bind it to the system
+    # runtime under /opt/rocm instead, and every kernel launch then fails (two runtimes in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:       # pragma: no cover - the C ABI is usable without torch
+        pass
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

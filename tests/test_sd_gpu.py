@@ -220,3 +220,37 @@ def test_sdxl_pipeline_surface(dev, monkeypatch):
             model_io.load_unet("no/such-model")
     finally:
         model_io._MODELS[key] = saved
+
+
+def test_sd21_pipeline_cfg_surface(dev, monkeypatch):
+    """StableDiffusion (SD 2.1-base route of flux_app.py:73-81) end to end on a patched-in small UNet / VAE with the REAL
+    OpenCLIP-H-style text tower (1024 wide, exact-erf gelu, 2 layers here): classifier-free guidance doubles the batch
+    (text first, negative second, __init__.py:67-82), the negative prompt changes the result, same seed -> same latents,
+    and one captured UNet-step graph serves all steps."""
+    import warnings
+    from flux_generator_amd import stable_diffusion as sd
+    from flux_generator_amd.stable_diffusion import model_io
+    from flux_generator_amd.stable_diffusion.config import AutoencoderConfig, UNetConfig
+    key = "stabilityai/stable-diffusion-2-1-base"
+    kw = tiny_unet_cfg(False)
+    kw.update(cross_attention_dim=(1024, 1024))
+    monkeypatch.setitem(model_io._MODELS, key, {**model_io._MODELS[key], "unet_config": UNetConfig(**kw),
+                                                "vae_config": AutoencoderConfig(block_out_channels=(128, 128), layers_per_block=1,
+                                                                                scaling_factor=0.18215)})
+    monkeypatch.setitem(model_io._TEXT_CONFIGS, (key, "text_encoder"),
+                        {**model_io._TEXT_CONFIGS[(key, "text_encoder")], "num_layers": 2})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe = sd.StableDiffusion(key, float16=True, device=str(dev))
+    cond = pipe._get_text_conditioning("a photo of a cat", n_images=2, cfg_weight=7.5, negative_text="blurry")
+    assert cond.shape[0] == 4 and cond.shape[2] == 1024            # [text x2, negative x2]
+    kwargs = dict(n_images=2, num_steps=3, cfg_weight=7.5, latent_size=(16, 16))
+    a = list(pipe.generate_latents("a photo of a cat", seed=1, **kwargs))
+    b = list(pipe.generate_latents("a photo of a cat", seed=1, **kwargs))
+    c = list(pipe.generate_latents("a photo of a cat", negative_text="blurry, low quality", seed=1, **kwargs))
+    assert len(a) == 3 and a[-1].shape == (2, 16, 16, 4) and bool(torch.isfinite(a[-1].float()).all())
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[-1], c[-1]), "the negative prompt has no effect under CFG"
+    assert len([k for k in pipe._graphs if k[0] == "step"]) == 1
+    img = pipe.decode(a[-1])
+    assert img.shape == (2, 32, 32, 3) and float(img.min()) >= 0 and float(img.max()) <= 1
