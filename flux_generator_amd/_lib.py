@@ -93,6 +93,8 @@ SIGNATURES = {
     # fp8 path
     "fluxhip_quantize_rows_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     "fluxhip_quantize_rows_fp8_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "fluxhip_ln_modulate_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "fluxhip_gemm_fp8": (c_int, [C.POINTER(GemmDesc), C.POINTER(Fp8Scales), c_void_p]),
     "fluxhip_gemm_fp8_tile_cfg": (c_int, [C.POINTER(GemmDesc)]),
     # fp32-faithful ("bf16x3") VAE path

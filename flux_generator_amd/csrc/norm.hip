@@ -10,12 +10,16 @@ namespace {
 // 267,300; nn.LayerNorm(affine=False, eps=1e-6): biased variance, fp32 statistics)
 // One wave per token row; NCH = ceil(D / 512) 16-byte chunks per lane kept in registers.
 // ---------------------------------------------------------------------------------------------
-template <int NCH>
+// Q8: the modulated row is written as OCP e4m3fn bytes with ONE float32 scale per row (max|row| / 448) instead of bf16 —
+// the per-token activation quantisation of the fp8 path (fluxhip_gemm_fp8) fused into its producer: the row is already in
+// this wave's registers, so the separate quantise pass (read bf16 row, write fp8 row) and its launch disappear.  The values
+// are rounded to bf16 first, exactly like the two-kernel sequence, so both give bit-identical bytes and scales.
+template <int NCH, bool Q8 = false>
 __global__ __launch_bounds__(512) void ln_modulate_kernel(
     const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int Tr, int D, int S,
     long long x_bstride, long long out_bstride, const bf16_t* __restrict__ shift_txt,
     const bf16_t* __restrict__ scale_txt, const bf16_t* __restrict__ shift_img,
-    const bf16_t* __restrict__ scale_img, long long mod_bstride, float eps) {
+    const bf16_t* __restrict__ scale_img, long long mod_bstride, float eps, float* __restrict__ row_scale = nullptr) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= (long long)B * Tr) return;
@@ -69,6 +73,7 @@ __global__ __launch_bounds__(512) void ln_modulate_kernel(
     }
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int c = lane + i * 64;
@@ -82,8 +87,32 @@ __global__ __launch_bounds__(512) void ln_modulate_kernel(
         float y0 = rbf(rbf(1.f + bf_lo(scw[i][e])) * n0) + bf_lo(shw[i][e]);
         float y1 = rbf(rbf(1.f + bf_hi(scw[i][e])) * n1) + bf_hi(shw[i][e]);
         o[e] = pack_bf16x2(y0, y1);
+        if constexpr (Q8) {
+          v[i][2 * e] = bf_lo(o[e]);                 // the bf16-rounded outputs replace the inputs in registers
+          v[i][2 * e + 1] = bf_hi(o[e]);
+          amax = fmaxf(amax, fmaxf(fabsf(v[i][2 * e]), fabsf(v[i][2 * e + 1])));
+        }
       }
-      *((u32x4*)orow + c) = o;
+      if constexpr (!Q8) *((u32x4*)orow + c) = o;
+    }
+  }
+  if constexpr (Q8) {
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) row_scale[row] = sc;
+    uint8_t* qrow = (uint8_t*)out + (b * out_bstride + (long long)t * D);      // strides in ELEMENTS = bytes here
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int c = lane + i * 64;
+      if (c < nchunk) {
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4] * inv, v[i][5] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][6] * inv, v[i][7] * inv, w1, true);
+        *(u32x2*)(qrow + c * 8) = u32x2{(uint32_t)w0, (uint32_t)w1};
+      }
     }
   }
 }
@@ -188,11 +217,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(
 
 }  // namespace
 
-extern "C" int fluxhip_ln_modulate_bf16(const void* x, void* out, int B, int Tr, int D, int S,
-                                        int64_t x_bstride, int64_t out_bstride,
-                                        const void* shift_txt, const void* scale_txt,
-                                        const void* shift_img, const void* scale_img,
-                                        int64_t mod_bstride, float eps, void* stream) {
+static int ln_modulate_launch(const void* x, void* out, float* row_scale, int B, int Tr, int D, int S,
+                              int64_t x_bstride, int64_t out_bstride, const void* shift_txt, const void* scale_txt,
+                              const void* shift_img, const void* scale_img, int64_t mod_bstride, float eps, void* stream) {
   if (!x || !out || !shift_img || !scale_img || B < 1 || Tr < 1 || D < 8 || D % 8 || D > 4096)
     return FLUXHIP_EINVAL;
   if (S > 0 && (!shift_txt || !scale_txt)) return FLUXHIP_EINVAL;
@@ -203,11 +230,19 @@ extern "C" int fluxhip_ln_modulate_bf16(const void* x, void* out, int B, int Tr,
   dim3 grid((unsigned)((rows + wpb - 1) / wpb)), block(wpb * 64);
   hipStream_t s = (hipStream_t)stream;
   const int nch = (D + 511) / 512;
-#define LN_LAUNCH(NCH)                                                                            \
-  hipLaunchKernelGGL((ln_modulate_kernel<NCH>), grid, block, 0, s, (const bf16_t*)x,              \
-                     (bf16_t*)out, B, Tr, D, S, (long long)x_bstride, (long long)out_bstride,     \
-                     (const bf16_t*)shift_txt, (const bf16_t*)scale_txt, (const bf16_t*)shift_img, \
-                     (const bf16_t*)scale_img, (long long)mod_bstride, eps)
+#define LN_LAUNCH(NCH)                                                                                  \
+  do {                                                                                                  \
+    if (row_scale)                                                                                      \
+      hipLaunchKernelGGL((ln_modulate_kernel<NCH, true>), grid, block, 0, s, (const bf16_t*)x,          \
+                         (bf16_t*)out, B, Tr, D, S, (long long)x_bstride, (long long)out_bstride,       \
+                         (const bf16_t*)shift_txt, (const bf16_t*)scale_txt, (const bf16_t*)shift_img,  \
+                         (const bf16_t*)scale_img, (long long)mod_bstride, eps, row_scale);             \
+    else                                                                                                \
+      hipLaunchKernelGGL((ln_modulate_kernel<NCH, false>), grid, block, 0, s, (const bf16_t*)x,         \
+                         (bf16_t*)out, B, Tr, D, S, (long long)x_bstride, (long long)out_bstride,       \
+                         (const bf16_t*)shift_txt, (const bf16_t*)scale_txt, (const bf16_t*)shift_img,  \
+                         (const bf16_t*)scale_img, (long long)mod_bstride, eps, (float*)nullptr);       \
+  } while (0)
   if (nch <= 1) LN_LAUNCH(1);
   else if (nch <= 2) LN_LAUNCH(2);
   else if (nch <= 4) LN_LAUNCH(4);
@@ -215,6 +250,24 @@ extern "C" int fluxhip_ln_modulate_bf16(const void* x, void* out, int B, int Tr,
   else LN_LAUNCH(8);
 #undef LN_LAUNCH
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_ln_modulate_bf16(const void* x, void* out, int B, int Tr, int D, int S,
+                                        int64_t x_bstride, int64_t out_bstride,
+                                        const void* shift_txt, const void* scale_txt,
+                                        const void* shift_img, const void* scale_img,
+                                        int64_t mod_bstride, float eps, void* stream) {
+  return ln_modulate_launch(x, out, nullptr, B, Tr, D, S, x_bstride, out_bstride, shift_txt, scale_txt, shift_img,
+                            scale_img, mod_bstride, eps, stream);
+}
+
+extern "C" int fluxhip_ln_modulate_fp8(const void* x, void* out, void* row_scale, int B, int Tr, int D, int S,
+                                       int64_t x_bstride, int64_t out_bstride, const void* shift_txt,
+                                       const void* scale_txt, const void* shift_img, const void* scale_img,
+                                       int64_t mod_bstride, float eps, void* stream) {
+  if (!row_scale || D % 16) return FLUXHIP_EINVAL;
+  return ln_modulate_launch(x, out, (float*)row_scale, B, Tr, D, S, x_bstride, out_bstride, shift_txt, scale_txt,
+                            shift_img, scale_img, mod_bstride, eps, stream);
 }
 
 extern "C" int fluxhip_qk_norm_rope_bf16(const void* qkv, int ld, int B, int T, int S, int H,

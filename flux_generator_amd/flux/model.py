@@ -293,7 +293,8 @@ class Flux:
             """fp8 variant of a block Linear over the packed token buffer: quantise the bf16 input rows `src`
             [B*T, K] per token into the shared scratch, then one fluxhip_gemm_fp8 launch.  `groups` as for gemm() with
             A given as the ROW offset of the group inside a batch (txt rows first); wnames = weight names per group."""
-            call(lib.fluxhip_quantize_rows_fp8, src, ptr["a8"], ptr["asc"], B * T, K, K)
+            if src is not None:      # None: the producer (fluxhip_ln_modulate_fp8) already wrote the e4m3 rows + scales
+                call(lib.fluxhip_quantize_rows_fp8, src, ptr["a8"], ptr["asc"], B * T, K, K)
             gs, a_sc, w_sc = [], [], []
             for g, wn in zip(groups, wnames):
                 wq, wscale = self._w8[wn]
@@ -370,15 +371,26 @@ class Flux:
             gemm8(src, K, gs, wn, N, ldc, epi)
 
         F8 = self.fp8
+
+        def ln_mod(shift_txt, scale_txt, shift_img, scale_img, S_):
+            """LayerNorm + modulate of the whole token buffer -> xm (bf16), or, in fp8 mode, straight to the e4m3 rows and
+            per-token scales the next GEMM reads (the quantisation is fused into the producer; returns the GEMM's src)."""
+            if F8:
+                call(lib.fluxhip_ln_modulate_fp8, ptr["x"], ptr["a8"], ptr["asc"], B, T, D, S_, T * D, T * D,
+                     shift_txt, scale_txt, shift_img, scale_img, NM, 1e-6)
+                return None
+            call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, S_, T * D, T * D,
+                 shift_txt, scale_txt, shift_img, scale_img, NM, 1e-6)
+            return ptr["xm"]
+
         for i in range(P.depth):                                              # flux/layers.py:181-231
             p = f"double_blocks.{i}"
             if i == JOIN_AT and split_rows < NM:
                 plan.append(("join", ()))
             io, to = self.mod_off[f"{p}.img_mod.lin"], self.mod_off[f"{p}.txt_mod.lin"]
-            call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, S, T * D, T * D,
-                 mp + to * e, mp + (to + D) * e, mp + io * e, mp + (io + D) * e, NM, 1e-6)
+            src = ln_mod(mp + to * e, mp + (to + D) * e, mp + io * e, mp + (io + D) * e, S)
             if F8:
-                two_streams8(ptr["xm"], D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", 3 * D, prefix=p)
+                two_streams8(src, D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", 3 * D, prefix=p)
             else:
                 gemm(two_streams(ptr["xm"], D, T * D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", prefix=p), B, 3 * D, D, D, 3 * D)
             call(lib.fluxhip_qk_norm_rope_bf16, ptr["qkv"], 3 * D, B, T, S, H,
@@ -393,10 +405,9 @@ class Flux:
             else:
                 gemm(two_streams(ptr["attn"], D, T * D, ptr["x"], D, T * D, "attn.proj", res=ptr["x"], gate_off=2 * D,
                                  i_off=io, t_off=to, prefix=p), B, D, D, D, D, EPI_GATE_RES)
-            call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, S, T * D, T * D,
-                 mp + (to + 3 * D) * e, mp + (to + 4 * D) * e, mp + (io + 3 * D) * e, mp + (io + 4 * D) * e, NM, 1e-6)
+            src = ln_mod(mp + (to + 3 * D) * e, mp + (to + 4 * D) * e, mp + (io + 3 * D) * e, mp + (io + 4 * D) * e, S)
             if F8:
-                two_streams8(ptr["xm"], D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", mlp, EPI_GELU_TANH, prefix=p)
+                two_streams8(src, D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", mlp, EPI_GELU_TANH, prefix=p)
                 two_streams8(ptr["hmlp"], mlp, ptr["x"], D, T * D, "mlp.layers.2", D, EPI_GATE_RES, res=ptr["x"],
                              gate_off=5 * D, i_off=io, t_off=to, prefix=p)
             else:
@@ -408,10 +419,9 @@ class Flux:
         for i in range(P.depth_single_blocks):                                # flux/layers.py:262-284
             p = f"single_blocks.{i}"
             o = self.mod_off[f"{p}.modulation.lin"]
-            call(lib.fluxhip_ln_modulate_bf16, ptr["x"], ptr["xm"], B, T, D, 0, T * D, T * D,
-                 None, None, mp + o * e, mp + (o + D) * e, NM, 1e-6)
+            src = ln_mod(None, None, mp + o * e, mp + (o + D) * e, 0)
             if F8:
-                gemm8(ptr["xm"], D, [dict(row0=0, bias=wo(f"{p}.linear1.bias"), C=ptr["qkv"], c_bstride=T * 3 * D, M=T)],
+                gemm8(src, D, [dict(row0=0, bias=wo(f"{p}.linear1.bias"), C=ptr["qkv"], c_bstride=T * 3 * D, M=T)],
                       [f"{p}.linear1"], 3 * D + mlp, 3 * D, EPI_SPLIT_GELU, n_split=3 * D, C2=ptr["cat"], ldc2=D + mlp,
                       c2_bstride=T * (D + mlp), c2_coloff=D)
             else:

@@ -288,6 +288,14 @@ int fluxhip_quantize_rows_fp8(const void* x, void* out, void* scale, int64_t row
 /* float32 [rows][K] source (weights kept in a wider master dtype), same output. */
 int fluxhip_quantize_rows_fp8_f32(const void* x, void* out, void* scale, int64_t rows, int K, int64_t ld, void* stream);
 
+/* fluxhip_ln_modulate_bf16 with the per-token e4m3 quantisation fused: out is e4m3fn [B][Tr][D] (out_bstride in
+ * elements = bytes), row_scale float32 [B*Tr] (row (b,t) at b*Tr + t).  Bit-identical to ln_modulate_bf16 followed by
+ * fluxhip_quantize_rows_fp8, without the bf16 round trip through HBM and without the second launch. */
+int fluxhip_ln_modulate_fp8(const void* x, void* out, void* row_scale, int B, int Tr, int D, int S,
+                            int64_t x_bstride, int64_t out_bstride, const void* shift_txt, const void* scale_txt,
+                            const void* shift_img, const void* scale_img, int64_t mod_bstride, float eps,
+                            void* stream);
+
 typedef struct fluxhip_fp8_scales {
   const void* a_scale[2];   /* float32 [nbatch][M] per group: one per row of A                     */
   const void* w_scale[2];   /* float32 [N] per group: one per row of W (output channel)            */

@@ -183,3 +183,24 @@ def test_full_size_fp8_properties(dev):
     gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(ws["pred"], a)
+
+
+def test_ln_modulate_fp8_fused_is_bit_identical(dev):
+    """fluxhip_ln_modulate_fp8 (quantisation fused into the producer) == fluxhip_ln_modulate_bf16 followed by
+    fluxhip_quantize_rows_fp8, byte for byte and scale for scale."""
+    from flux_generator_amd import _lib, ops
+    B, S, L, D = 2, 24, 40, 3072
+    T = S + L
+    x = rnd(B, T, D, seed=1, scale=1.5)
+    x[0, 3] = 0.0                                               # a constant row: LN output 0 + shift
+    mods = rnd(B, 4 * D, seed=2, scale=0.5)
+    mp, e = mods.data_ptr(), 2
+    xm = torch.empty(B, T, D, dtype=BF, device=dev)
+    ops.ln_modulate(x, xm, B, T, D, S, T * D, T * D, mp, mp + D * e, mp + 2 * D * e, mp + 3 * D * e, 4 * D)
+    q_ref, s_ref = ops.quantize_rows_fp8(xm.view(B * T, D))
+    q = torch.empty(B * T, D, dtype=torch.uint8, device=dev)
+    sc = torch.empty(B * T, dtype=torch.float32, device=dev)
+    rc = _lib.load().fluxhip_ln_modulate_fp8(x.data_ptr(), q.data_ptr(), sc.data_ptr(), B, T, D, S, T * D, T * D, mp, mp + D * e,
+                                             mp + 2 * D * e, mp + 3 * D * e, 4 * D, 1e-6, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(sc, s_ref) and torch.equal(q, q_ref)
