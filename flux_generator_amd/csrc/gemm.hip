@@ -50,7 +50,7 @@ const TileCfg kCfgs[] = {
     make_cfg_f8<64, 128, 2, 2, 2, 0>(),   // 3
     make_cfg_x3_f8<64, 64, 2, 2, 2, 0>(),    // 4: tiny problems (N=64 final layer)
     make_cfg<256, 128, 4, 2, 2, 0>(),  // 5: 8 waves, 96 KiB
-    make_cfg<256, 256, 2, 4, 2, 0>(),  // 6: 8 waves x (128x64), 128 KiB
+    make_cfg_f8<256, 256, 2, 4, 2, 0>(),  // 6: 8 waves x (128x64), 128 KiB (fp8: the one 256x256 tile that fits 256 registers)
     make_cfg_x3<128, 128, 2, 2, 2, 1>(),  // 7: fragment-pipelined variants of 1,2,3,5,6
     make_cfg_x3<128, 64, 2, 2, 2, 1>(),   // 8
     make_cfg_x3<64, 128, 2, 2, 2, 1>(),   // 9
@@ -119,10 +119,12 @@ const Cand kCands[] = {
     {46, 1, 0.748f, 12.1f},   // 256x128, spread LDS-DMA + fragment reads, 3 + 4 ring
     {55, 1, 0.787f, 10.9f},   // 128x256, ping-pong
     {47, 1, 0.564f, 5.71f},   // 128x128, 8 waves, spread reads
-    {7, 2, 0.903f, 10.2f},    // 128x128, 4 waves, 2 blocks/CU
-    {8, 2, 0.847f, 0.30f},    // 128x64
-    {9, 2, 0.672f, 2.90f},    // 64x128
-    {4, 2, 0.483f, 1.15f},    // 64x64
+    // two blocks per CU: refitted in round 2 on the SDXL UNet shapes (M = 16384 / 4096, K = 640 .. 5120, many rounds), where the
+    // round-1 constants made the picker prefer 128x64 over 256x160 for the 16384 x 1280 x 640 q/k projection (411 vs 632 TFLOP/s)
+    {7, 2, 1.010f, 5.5f},     // 128x128, 4 waves, 2 blocks/CU
+    {8, 2, 0.920f, 3.8f},     // 128x64
+    {9, 2, 0.672f, 2.90f},    // 64x128 (round-1 fit kept: with cold K = 3072 weights it must stay behind the 128x128 8-wave tile)
+    {4, 2, 0.637f, 0.15f},    // 64x64
 };
 
 // The implicit-GEMM (conv) loader has its own table (tools/conv_tune.py): its K-step carries the tap /
@@ -151,9 +153,15 @@ const Cand kX3ConvCands[] = {
 // the simple-ring tiles for small shapes.
 // (the 256x256 / 256x224 / 256x192 ping-pong tiles do not fit 256 registers with 8-register fp8 operand tuples and
 //  spill: a spilled LDS-read destination is copied before the data lands, so they are not instantiated for fp8)
-const Cand kF8Cands[] = {
-    {54, 1, 0.819f, 14.3f}, {52, 1, 0.760f, 12.1f}, {55, 1, 0.787f, 10.9f}, {53, 1, 0.600f, 6.0f},  {1, 2, 1.000f, 10.2f},
-    {2, 2, 0.847f, 0.30f},  {3, 2, 0.672f, 2.90f},  {4, 2, 0.483f, 1.15f},
+const Cand kF8Cands[] = {          // (t_step per 128-byte K-step, t_fixed) fitted to TUNE_FP8=1 tools/gemm_tune.py, M = 17408 / 1280
+    {6, 1, 1.571f, 20.6f},   // 256x256, simple ring: 1.7-2.1 PFLOP/s on the large shapes
+    {55, 1, 0.927f, 10.1f},  // 128x256, ping-pong
+    {54, 1, 1.178f, 13.1f},  // 256x160  "
+    {52, 1, 1.137f, 11.1f},  // 256x128  "
+    {53, 1, 0.815f, 2.8f},   // 128x128  "  (the N = 3072 shapes at batch 1: 1.0-1.5 PFLOP/s)
+    // two blocks per CU: the per-step times are for BOTH blocks resident (each runs at about half the single-block rate)
+    {1, 2, 1.70f, 9.2f},     // 128x128, simple ring
+    {2, 2, 1.70f, 0.30f},  {3, 2, 1.35f, 2.90f},  {4, 2, 0.97f, 1.15f},
 };
 
 // Split-K workspace (fluxhip_set_workspace): [kSkMaxTiles] int32 hand-off counters, then fp32 partial tiles.

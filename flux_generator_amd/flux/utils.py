@@ -67,7 +67,9 @@ def load_flow_model(name: str, hf_download: bool = True, device="cuda", seed: in
     if spec.ckpt_path is not None:
         model.load_weights(model.sanitize(_load_safetensors(spec.ckpt_path)))
     else:
-        warnings.warn(f"{name}: no checkpoint configured (set FLUX_SCHNELL / FLUX_DEV); using random-init weights")
+        # the reference would hf_hub_download() here; this build has no hub access, so `hf_download` cannot be honoured
+        warnings.warn(f"{name}: no checkpoint configured (set FLUX_SCHNELL / FLUX_DEV; hub download is not available "
+                      "in this build); using random-init weights")
         model.init_random(seed)
     return model
 
@@ -79,7 +81,8 @@ def load_ae(name: str, hf_download: bool = True, device="cuda", seed: int = 1) -
     if spec.ae_path is not None:
         ae.load_weights(ae.sanitize(_load_safetensors(spec.ae_path)))   # strict: encoder.* keys are skipped explicitly
     else:
-        warnings.warn(f"{name}: no AE checkpoint configured (set AE); using random-init weights")
+        warnings.warn(f"{name}: no AE checkpoint configured (set AE; hub download is not available in this build); "
+                      "using random-init weights")
         ae.init_random(seed)
     return ae
 

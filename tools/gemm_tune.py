@@ -25,6 +25,8 @@ shapes = {  # name: (M, N, K, epi)
     "linear1": (M, 21504, 3072, 0),
     "linear2": (M, 3072, 15360, 2),
 }
+if os.environ.get("TUNE_SHAPES"):      # "name:M:N:K:epi,..." e.g. the SDXL UNet transformer GEMMs at batch 16
+    shapes = {t.split(":")[0]: tuple(int(v) for v in t.split(":")[1:]) for t in os.environ["TUNE_SHAPES"].split(",")}
 only = sys.argv[1:]  # optional list of cfg ids
 def _code(c):   # "41s2" = tile cfg 41 with split-K 2
     c = str(c)
@@ -43,12 +45,22 @@ for name, (m, n, k, epi) in shapes.items():
     out = torch.empty(m, n, dtype=BF, device=dev)
     ref = None
     row = {}
+    FP8 = bool(os.environ.get("TUNE_FP8"))       # fp8 kernels: e4m3 operands quantised once up front
+    if FP8:
+        xq, xs = ops.quantize_rows_fp8(x)
+        wqs = [ops.quantize_rows_fp8(w_) for w_ in ws]
+        _lin = ops.linear
+        ops_linear = lambda x_, w_, b_, **kw_: ops.linear_fp8(xq, xs, *wqs[[id(t) for t in ws].index(id(w_))], b_, **kw_)   # noqa: E731
+    else:
+        ops_linear = ops.linear
     for c in cfgs:
         try:
             kw = dict(epi=epi, out=out, tile_cfg=c)
+            if c == 0:
+                kw.pop("tile_cfg")          # 0 = whatever the picker chooses
             if epi == 2:
                 kw.update(res=r, gate=gate)
-            ops.linear(x, w, b, **kw)
+            ops_linear(x, w, b, **kw)
             torch.cuda.synchronize()
             if ref is None:
                 ref = out.float().clone()
@@ -56,12 +68,12 @@ for name, (m, n, k, epi) in shapes.items():
                 err = float((out.float() - ref).abs().max())
                 assert err < 0.1, (name, c, err)
             for _ in range(3):
-                ops.linear(x, w, b, **kw)
+                ops_linear(x, w, b, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n_it = 20
             e0.record()
             for it in range(n_it):
-                ops.linear(x, ws[it % nrot], b, **kw)
+                ops_linear(x, ws[it % nrot], b, **kw)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n_it
