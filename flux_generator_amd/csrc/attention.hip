@@ -169,6 +169,10 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
   __syncthreads();
 
   const int nstages = (ntiles + KS - 1) / KS;
+  // Static priority for the second-dispatched wave set (MI355X guide, "two waves per SIMD", item 4): the younger wave of a
+  // SIMD loses every VALU arbitration to its older partner; one s_setprio for that half before the loop (no per-phase
+  // flips) lets it take the older half's timing.  FLUXHIP_ATTN_PRIO=0 at build time of this experiment removes it.
+  if (KS == 2 && kp == 1) __builtin_amdgcn_s_setprio(1);
   for (int st = 0; st < nstages; ++st) {
     const int cur = st & 1;
     const bool more = st + 1 < nstages;
