@@ -15,12 +15,12 @@ with fp32 accumulation (stated in tests/test_sd_gpu.py).
 from __future__ import annotations
 
 import math
-from typing import Dict, Iterable, List, Optional, Tuple, Union
+from typing import Dict, Optional, Tuple, Union
 
 import torch
 
 from .. import _lib, ops
-from ..ops import EPI_BIAS, EPI_GATE_RES, EPI_GEGLU, FluxHipError, make_gemm_desc
+from ..ops import EPI_GATE_RES, EPI_GEGLU, FluxHipError, make_gemm_desc
 from .config import UNetConfig
 
 BF16 = torch.bfloat16

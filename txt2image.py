@@ -7,7 +7,6 @@ import argparse
 import os
 import sys
 
-import numpy as np
 import torch
 from PIL import Image
 
