@@ -103,6 +103,8 @@ SIGNATURES = {
     "fluxhip_gemm_x3": (c_int, [C.POINTER(GemmX3Desc), c_void_p]),
     "fluxhip_conv2d_x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64]
                           + [c_int] * 9 + [c_void_p, c_void_p]),
+    "fluxhip_conv_up2x_x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64]
+                             + [c_int] * 5 + [c_void_p, c_void_p]),
     "fluxhip_groupnorm_silu_x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64] + [c_int] * 4
                                   + [c_float, c_int, c_void_p, c_int64, c_void_p]),
     "fluxhip_softmax_rows_x3": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_void_p]),

@@ -475,3 +475,42 @@ extern "C" int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int
   int cfg = forced > 0 ? forced : pick_cfg(&t.M, 1, 1, Cout, p.K, true, true);
   return launch(p, cfg, true, (hipStream_t)stream, true);
 }
+
+// (nearest-upsample x2 -> 3x3 conv, pad 1) as four 2x2 convs of the low-res input, one per output-pixel parity:
+// the 3x3 taps that read the same source pixel are pre-summed in `w4` ([4][Cout][2][2][Cin], parity = 2*dy + dx;
+// ops.subpixel_weights builds it in float32 before the hi/lo split), so the MFMA work is 4/9 of the fused-upsample
+// loader's.  Replaces Upsample + Conv2d of flux/autoencoder.py:117-122 (and stable_diffusion/vae.py) exactly up to
+// float32 rounding of the pre-summed weights.
+extern "C" int fluxhip_conv_up2x_x3(const void* x, int64_t x_lo, const void* w4, int64_t w_lo, const void* bias,
+                                    void* out, int64_t out_lo, int B, int Hs, int Ws, int Cin, int Cout,
+                                    const void* zero16, void* stream) {
+  if (!x || !w4 || !out || !zero16) return FLUXHIP_EINVAL;
+  if (Cin % 64 || Cout % 4 || (x_lo | w_lo) % 8 || out_lo % 4) return FLUXHIP_EINVAL;
+  static const int forced = [] { const char* e = getenv("FLUXHIP_CONV_X3_CFG"); return e ? atoi(e) : 0; }();
+  GemmParams p{};
+  p.cv.X = (const bf16_t*)x;
+  p.cv.zero = (const bf16_t*)zero16;
+  p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Hs; p.cv.Wo = Ws;
+  p.cv.Cin = Cin; p.cv.ksize = 2; p.cv.stride = 1; p.cv.pad = 0; p.cv.ups = 0;
+  p.cv.sub2 = 1;
+  GemmGroup& t = p.g[0];
+  t.A = (const bf16_t*)x;
+  t.W = (const bf16_t*)w4;
+  t.w_bstride = (long long)Cout * 4 * Cin;          // one 2x2 weight set per parity ("batch")
+  t.bias = (const bf16_t*)bias;
+  t.C = (bf16_t*)out;
+  t.M = B * Hs * Ws;
+  p.ngroups = 1;
+  p.nbatch = 4;
+  p.N = Cout;
+  p.K = 4 * Cin;
+  p.lda = Cin;
+  p.ldc = Cout;
+  p.epi = EPI_BIAS;
+  p.alpha = 1.f;
+  p.a_lo = x_lo;
+  p.w_lo = w_lo;
+  p.c_lo = out_lo;
+  int cfg = forced > 0 ? forced : pick_cfg(&t.M, 1, 4, Cout, p.K, true, true);
+  return launch(p, cfg, true, (hipStream_t)stream, true);
+}

@@ -56,11 +56,20 @@ struct ConvGeom {        // implicit-GEMM A loader (NHWC activations)
   int Hs, Ws;            // stored (source) resolution
   int Ho, Wo;            // output resolution
   int Cin;               // multiple of 64
-  int ksize;             // 1 or 3
+  int ksize;             // 1, 2 or 3
   int stride;            // 1 or 2
   int pad;               // 0 or 1
   int ups;               // 1: input is nearest-upsampled x2 on the fly
+  // Sub-pixel form of (nearest-upsample x2 -> 3x3 conv): output pixels of parity (sdy, sdx) are a 2x2 conv of the
+  // LOW-res input (the 3x3 taps that land on the same source pixel are pre-summed in the weights: 4/9 of the
+  // MFMA work).  The four parities are the "batches" of one launch (nbatch = 4, w_bstride = one 2x2 weight set,
+  // parity innermost in the tile order so that the four tiles sharing an input window run together): the window's
+  // top-left is (y + sdy - 1, x + sdx - 1) and output row m = (img, y, x) is stored at (img, 2y + sdy, 2x + sdx) of
+  // the [B][2Ho][2Wo] output.  FLAG_SPLIT kernels only.
+  int sub2;
 };
+
+DEVINL int conv_tap_row(int ksize, int tap) { return ksize == 3 ? tap / 3 : (ksize == 2 ? tap >> 1 : 0); }
 
 struct GemmParams {
   GemmGroup g[2];
@@ -193,8 +202,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
   const long long w_bs = g1 ? p.g[1].w_bstride : p.g[0].w_bstride;
   const int Mg = g1 ? p.g[1].M : p.g[0].M;
   const int tpb = g1 ? p.g[1].tiles_m : p.g[0].tiles_m;
-  const int b = tm / tpb;
-  const int m0 = (tm % tpb) * BM;
+  int b = tm / tpb;
+  int m0 = (tm % tpb) * BM;
+  int sdy = 0, sdx = 0, c_oy = 0, c_ox = 0;         // sub-pixel conv: parity of this tile's output pixels
+  if (AMODE == 1 && p.cv.sub2) {
+    b = tm & 3;
+    m0 = (tm >> 2) * BM;
+    sdy = b >> 1; sdx = b & 1;
+    c_oy = sdy - 1; c_ox = sdx - 1;
+  }
   const int n0 = tn * BN;
   const int N = p.N, K = p.K;
   constexpr bool X3 = (FLAGS & FLAG_SPLIT) != 0;
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       int rem = pix - bb * hw;
       int y = rem / p.cv.Wo;
       int x = rem - y * p.cv.Wo;
-      const int y0 = y * p.cv.stride - p.cv.pad, x0 = x * p.cv.stride - p.cv.pad;
+      const int y0 = y * p.cv.stride - p.cv.pad + c_oy, x0 = x * p.cv.stride - p.cv.pad + c_ox;
       const long long img = (long long)bb * p.cv.Hs * p.cv.Ws * p.cv.Cin;      // elements; Cin % 64 == 0
       if (p.cv.ups) {
         cyx[i] = (y0 << 16) | (x0 & 0xffff);
@@ -276,7 +292,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       } else {
         int mask = 0;
         for (int t = 0; t < p.cv.ksize * p.cv.ksize; ++t) {
-          const int yy = y0 + (p.cv.ksize == 3 ? t / 3 : 0), xx = x0 + (p.cv.ksize == 3 ? t % 3 : 0);
+          const int ty = conv_tap_row(p.cv.ksize, t);
+          const int yy = y0 + ty, xx = x0 + t - ty * p.cv.ksize;
           mask |= ((yy >= 0) & (yy < p.cv.Hs) & (xx >= 0) & (xx < p.cv.Ws)) << t;
         }
         cyx[i] = mask;
@@ -308,8 +325,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       const int cch = ks / ntap;
       const int tap = ks - cch * ntap;
       const int c0 = cch << 6;
-      const int dy = (p.cv.ksize == 3) ? tap / 3 : 0;
-      const int dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
+      const int dy = conv_tap_row(p.cv.ksize, tap);
+      const int dx = tap - dy * p.cv.ksize;
       if (!p.cv.ups) {
         const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj;   // wave-uniform
 #pragma unroll
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
             const int hw = p.cv.Ho * p.cv.Wo;
             const int bb = grow / hw, rem = grow - bb * hw;
             const int y = rem / p.cv.Wo, x = rem - y * p.cv.Wo;
-            const int y0 = y * p.cv.stride - p.cv.pad, x0 = x * p.cv.stride - p.cv.pad;
+            const int y0 = y * p.cv.stride - p.cv.pad + c_oy, x0 = x * p.cv.stride - p.cv.pad + c_ox;
             const long long img = (long long)bb * p.cv.Hs * p.cv.Ws * p.cv.Cin;
             if (p.cv.ups) {
               gyx[i] = (y0 << 16) | (x0 & 0xffff);
@@ -529,7 +546,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
             } else {
               int mask = 0;
               for (int t = 0; t < p.cv.ksize * p.cv.ksize; ++t) {
-                const int yy = y0 + (p.cv.ksize == 3 ? t / 3 : 0), xx = x0 + (p.cv.ksize == 3 ? t % 3 : 0);
+                const int ty = conv_tap_row(p.cv.ksize, t);
+          const int yy = y0 + ty, xx = x0 + t - ty * p.cv.ksize;
                 mask |= ((yy >= 0) & (yy < p.cv.Hs) & (xx >= 0) & (xx < p.cv.Ws)) << t;
               }
               gyx[i] = mask;
@@ -546,8 +564,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
             const int cch = ks / ntap;
             tap = ks - cch * ntap;
             c0 = cch << 6;
-            dy = (p.cv.ksize == 3) ? tap / 3 : 0;
-            dx = (p.cv.ksize == 3) ? tap - dy * 3 : 0;
+            dy = conv_tap_row(p.cv.ksize, tap);
+            dx = tap - dy * p.cv.ksize;
           }
 #pragma unroll
           for (int i = 0; i < PA; ++i) {
@@ -866,6 +884,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       const int m = m0 + wm * WTM + i * 16 + r16;
       if (m >= Mg) continue;
       const float rb = (fbias && p.row_bias) ? fbias[m] : 0.f;
+      long long orow = m;
+      if (AMODE == 1 && p.cv.sub2) {               // sub-pixel conv: (b, y, x) -> (b, 2y + sdy, 2x + sdx)
+        const int hw = p.cv.Ho * p.cv.Wo;
+        const int bb = m / hw, rem = m - bb * hw;
+        const int y = rem / p.cv.Wo, x = rem - y * p.cv.Wo;
+        orow = ((long long)bb * (2 * p.cv.Ho) + 2 * y + sdy) * (2 * p.cv.Wo) + 2 * x + sdx;
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
@@ -873,7 +898,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
         f32x4 v = acc[i][j] * alpha;
         if (fbias && !p.row_bias) v += *(const f32x4*)(fbias + n4);
         v += rb;
-        const long long idx = (long long)b * c_bs + (long long)m * p.ldc + n4;
+        const long long idx = (long long)b * c_bs + orow * p.ldc + n4;
         if (p.out_f32) {
           *(f32x4*)((float*)gC + idx) = v;
           continue;

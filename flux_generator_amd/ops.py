@@ -399,6 +399,37 @@ def conv2d_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], strid
     return out
 
 
+def subpixel_weights(w: torch.Tensor) -> torch.Tensor:
+    """float32 3x3 weights [Cout,3,3,Cin] -> [4,Cout,2,2,Cin]: the four 2x2 kernels that (nearest-upsample x2 ->
+    3x3 conv, pad 1) applies to the low-res input, one per output-pixel parity 2*dy + dx.  Taps reading the same
+    source pixel are summed in float32 (dy = 0: rows {w0, w1+w2}; dy = 1: rows {w0+w1, w2}; same along x)."""
+    if w.dtype != torch.float32 or w.dim() != 4 or w.shape[1:3] != (3, 3):
+        raise ValueError("subpixel_weights: float32 [Cout,3,3,Cin] expected")
+    rows = (torch.stack([w[:, 0], w[:, 1] + w[:, 2]], 1), torch.stack([w[:, 0] + w[:, 1], w[:, 2]], 1))   # [Cout,2,3,Cin]
+    par = []
+    for dy in (0, 1):
+        r = rows[dy]
+        par.append(torch.stack([r[:, :, 0], r[:, :, 1] + r[:, :, 2]], 2))
+        par.append(torch.stack([r[:, :, 0] + r[:, :, 1], r[:, :, 2]], 2))
+    return torch.stack(par, 0).contiguous()
+
+
+def conv_up2x_x3(x: torch.Tensor, w4: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Upsample (nearest x2) + 3x3 conv in float32 as four 2x2 convs of the low-res split tensor x [2,B,H,W,Cin];
+    w4 = split_f32(subpixel_weights(w)) = [2,4,Cout,2,2,Cin]."""
+    _split_ok(x, "x"); _split_ok(w4, "w4")
+    _, B, Hs, Ws, Cin = x.shape
+    if w4.dim() != 6 or w4.shape[1] != 4 or w4.shape[3:5] != (2, 2) or w4.shape[5] != Cin:
+        raise ValueError("conv_up2x_x3: w4 must be [2,4,Cout,2,2,Cin]")
+    Cout = w4.shape[2]
+    if out is None:
+        out = torch.empty(2, B, Hs * 2, Ws * 2, Cout, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_conv_up2x_x3(_p(x[0]), x.stride(0), _p(w4[0]), w4.stride(0), _p(_f32c(b, "bias")),
+                                            _p(out[0]), out.stride(0), B, Hs, Ws, Cin, Cout,
+                                            _p(_zeros16(x.device)), _stream()), "fluxhip_conv_up2x_x3")
+    return out
+
+
 def groupnorm_silu_x3(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6,
                       silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _split_ok(x, "x")

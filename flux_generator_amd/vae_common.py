@@ -68,7 +68,8 @@ class ParamStore:
             raise ValueError(f"Missing parameters: {sorted(set(self.master) - seen)[:5]} ...")
 
     def get(self, name: str, kind: str) -> torch.Tensor:
-        """kind: "f32" master, "bf16" copy, "x3" split (hi, lo) planes."""
+        """kind: "f32" master, "bf16" copy, "x3" split (hi, lo) planes, "x3up" split planes of the sub-pixel form of
+        a 3x3 conv that follows a nearest x2 upsample (ops.subpixel_weights)."""
         t = self.master[name]
         if kind == "f32":
             return t
@@ -78,6 +79,8 @@ class ParamStore:
         src = t
         if name in self._pad64 and t.shape[-1] % 64:
             src = torch.nn.functional.pad(t, (0, 64 - t.shape[-1] % 64)).contiguous()
+        if kind == "x3up":
+            src = ops.subpixel_weights(src)
         d = src.to(BF16) if kind == "bf16" else ops.split_f32(src)
         self._derived[(name, kind)] = (t._version, d)
         return d
@@ -161,6 +164,8 @@ def attention(P: ParamStore, fp32: bool, p: str, x: torch.Tensor, norm: str, q: 
 
 
 def conv(P: ParamStore, fp32: bool, p: str, x: torch.Tensor, ups: bool = False) -> torch.Tensor:
+    if fp32 and ups:     # Upsample + conv as four 2x2 convs of the low-res input (4/9 of the MFMA work)
+        return ops.conv_up2x_x3(x, P.get(f"{p}.weight", "x3up"), P.get(f"{p}.bias", "f32"))
     if fp32:
         return ops.conv2d_x3(x, P.get(f"{p}.weight", "x3"), P.get(f"{p}.bias", "f32"), ups=ups)
     return ops.conv2d(x, P.get(f"{p}.weight", "bf16"), P.get(f"{p}.bias", "bf16"), ups=ups)

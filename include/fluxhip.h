@@ -256,6 +256,14 @@ int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int64_t w_lo, 
                       const void* res, int64_t res_lo, void* out, int64_t out_lo, int B, int Hs, int Ws,
                       int Cin, int Cout, int ksize, int stride, int pad, int ups, const void* zero16,
                       void* stream);
+/* Upsample (nearest x2) + Conv2d 3x3 pad 1 in float32 (flux/autoencoder.py:117-122; stable_diffusion/vae.py
+ * upsample path) in sub-pixel form: four 2x2 convs of the low-res input, one per output-pixel parity, on weights
+ * w4 = [4][Cout][2][2][Cin] in which the 3x3 taps that read the same source pixel are pre-summed (parity =
+ * 2*dy + dx; dy = 0: rows {w0, w1+w2}, dy = 1: rows {w0+w1, w2}; same along x).  4/9 of the MFMA work of the
+ * fused-upsample loader.  x: split [B][Hs][Ws][Cin]; out: split [B][2Hs][2Ws][Cout]; bias float32. */
+int fluxhip_conv_up2x_x3(const void* x, int64_t x_lo, const void* w4, int64_t w_lo, const void* bias, void* out,
+                         int64_t out_lo, int B, int Hs, int Ws, int Cin, int Cout, const void* zero16,
+                         void* stream);
 /* GroupNorm [+ SiLU] on a split NHWC tensor with float32 gamma / beta; float32 arithmetic throughout. */
 int fluxhip_groupnorm_silu_x3(const void* x, int64_t x_lo, const void* gamma, const void* beta, void* out,
                               int64_t out_lo, int B, int HW, int C, int G, float eps, int silu, void* ws,

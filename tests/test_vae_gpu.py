@@ -165,6 +165,30 @@ def test_conv3x3_x3(dev, Cin, Cout, hw, ups):
     assert rel_l2(ops.join_f32(y3), O.linear(x.double(), w1.double(), b.double()).float()) < X3
 
 
+@pytest.mark.parametrize("Cin,Cout,hw,B", [(512, 512, (8, 8), 2), (256, 256, (13, 7), 1), (128, 64, (32, 32), 3), (64, 128, (1, 1), 1)])
+def test_conv_up2x_x3(dev, Cin, Cout, hw, B):
+    """Upsample + 3x3 conv in sub-pixel form (four 2x2 convs of the low-res input on pre-summed taps) against the
+    float64 (upsample -> conv) of flux/autoencoder.py:117-122, borders included, and against the fused-upsample
+    loader it replaces."""
+    from flux_generator_amd import ops
+    x, w, b = frnd(B, *hw, Cin, seed=1), frnd(Cout, 3, 3, Cin, seed=2, scale=(9 * Cin) ** -0.5), frnd(Cout, seed=3)
+    ref = O.conv2d(O.upsample_nearest2(x).double(), w.double(), b.double()).float()
+    X = ops.split_f32(x.to(dev))
+    w4 = ops.subpixel_weights(w.to(dev))
+    assert w4.shape == (4, Cout, 2, 2, Cin)
+    assert torch.allclose(w4.sum((0, 2, 3)).cpu(), 4 * w.sum((1, 2)), rtol=1e-4, atol=1e-5)     # every tap lands in every parity exactly once
+    y = ops.conv_up2x_x3(X, ops.split_f32(w4), b.to(dev))
+    assert y.shape == (2, *ref.shape)
+    e = rel_l2(ops.join_f32(y), ref)
+    old = ops.join_f32(ops.conv2d_x3(X, ops.split_f32(w.to(dev)), b.to(dev), ups=True))
+    print(f"conv_up2x_x3 {Cin}->{Cout} {hw}: rel-L2 {e:.2e} (fused-upsample loader {rel_l2(old, ref):.2e})")
+    assert e < X3
+    with pytest.raises(ValueError):
+        ops.subpixel_weights(w.to(dev).to(BF))
+    with pytest.raises(ValueError):
+        ops.conv_up2x_x3(X, ops.split_f32(w.to(dev)), b.to(dev))
+
+
 @pytest.mark.parametrize("C,hw", [(512, (16, 16)), (256, (24, 40)), (128, (64, 64))])
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm_x3(dev, C, hw, silu):

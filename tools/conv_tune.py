@@ -33,6 +33,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             ms = e0.elapsed_time(e1) / 10
             Ho = H * 2 if ups else H
             out[f"{H}{'u' if ups else ''}:{Cin}->{Cout}"] = (round((3 if X3 else 1) * 2.0 * Ho * Ho * Cout * Cin * 9 / ms / 1e9), float(y.float().abs().mean()))
+            if X3 and ups:       # the sub-pixel form of the same op (4/9 of the MFMA work)
+                w4 = ops.split_f32(ops.subpixel_weights(ops.join_f32(w)))
+                for _ in range(3):
+                    y = ops.conv_up2x_x3(x, w4, b)
+                e0.record()
+                for _ in range(10):
+                    ops.conv_up2x_x3(x, w4, b, out=y)
+                e1.record(); torch.cuda.synchronize()
+                ms2 = e0.elapsed_time(e1) / 10
+                # quoted on the 9-tap flops of the op it replaces, so the row compares directly with the `u` row above
+                out[f"{H}u-subpixel:{Cin}->{Cout}"] = (round(3 * 2.0 * Ho * Ho * Cout * Cin * 9 / ms2 / 1e9), float(ops.join_f32(y).abs().mean()))
         except Exception as ex:
             out[f"{H}:{Cin}->{Cout}"] = ("ERR", 0)
     print("RESULT " + json.dumps(out))
