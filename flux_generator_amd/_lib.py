@@ -71,6 +71,7 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                           c_int, c_float, c_void_p]),
     "fluxhip_attention_d128_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
+    "fluxhip_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "fluxhip_timestep_embedding_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
     "fluxhip_rope_table_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "fluxhip_euler_step_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),

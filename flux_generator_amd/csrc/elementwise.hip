@@ -619,6 +619,24 @@ extern "C" int fluxhip_rope_table_bf16(const void* ids, void* out, int64_t ntok,
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 
+// ---- nn.silu on a bf16 vector (Modulation: lin(silu(vec)), flux/layers.py:136) --------------------
+// The GEMV applies silu to its input on the fly when it serves one step (silu_in = 1); when one pass serves several
+// steps' vectors (Flux.modulation_tables) the activation is taken out of the weight-streaming loop: same function,
+// same bf16 rounding, so both orders give identical bits.
+namespace {
+__global__ __launch_bounds__(256) void silu_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = f2bf(silu_f(bf2f(x[i])));
+}
+}  // namespace
+
+extern "C" int fluxhip_silu_bf16(const void* x, void* out, int64_t n, void* stream) {
+  if (!x || !out || n < 1) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL(silu_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)out, (long long)n);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
 // ---- fp32-faithful VAE path entry points ---------------------------------------------------------
 extern "C" int fluxhip_split_f32(const void* x, void* hi, void* lo, int64_t n, void* stream) {
   if (!x || !hi || !lo || n < 1) return FLUXHIP_EINVAL;

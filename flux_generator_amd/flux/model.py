@@ -66,6 +66,7 @@ class Flux:
             raise FluxHipError("Flux needs a HIP device: there is no CPU fallback for the denoise path")
         self.device = _lib.bind_device(device)
         self._side = None            # side stream of the launch plan (modulation GEMV under the first blocks)
+        self._t_cache = {}           # modulation_tables: device copies of the timestep groups seen so far
         _lib.load()
         self._alloc_parameters()
         self._ws: Dict[Tuple[int, int, int], dict] = {}
@@ -333,6 +334,7 @@ class Flux:
             plan.append(("side", (lib.fluxhip_small_linear_bf16,
                                   (ptr["vec"], self.mod_w.data_ptr() + split_rows * D * e, self.mod_b.data_ptr() + split_rows * e,
                                    mp + split_rows * e, B, NM - split_rows, D, 1, 0))))
+        plan.append(("mod_end", ()))     # everything up to here depends on (t, y, guidance) only: see modulation_tables
         # pe = EmbedND(ids)                                                    flux/model.py:123-124
         call(lib.fluxhip_rope_table_bf16, ptr["in_ids"], ptr["rope"], B * T, 3, P.axes_dim[0], P.axes_dim[1],
              P.axes_dim[2], float(P.theta))
@@ -481,7 +483,7 @@ class Flux:
         stream = torch.cuda.current_stream()
         recs = []
         for fn, args in ws["plan"]:
-            if fn in ("keepalive", "join"):
+            if fn in ("keepalive", "join", "mod_end"):
                 continue
             if fn == "side":        # timed in line here (the graph runs it on the side stream)
                 fn, args = args
@@ -511,11 +513,17 @@ class Flux:
         torch.cuda.synchronize()
         return [(l, e0.elapsed_time(e1), f) for l, e0, e1, f in recs]
 
-    def run_plan(self, ws: dict) -> None:
+    def run_plan(self, ws: dict, skip_mod: bool = False) -> None:
+        """Enqueue the launches of one forward on the current stream.  skip_mod: ws["mods"] already holds this step's
+        modulation table (modulation_tables), so the launches before the plan's "mod_end" marker are left out."""
         cur = torch.cuda.current_stream()
         stream = cur.cuda_stream
+        skipping = skip_mod
         for fn, args in ws["plan"]:
-            if fn == "keepalive":
+            if fn == "mod_end":
+                skipping = False
+                continue
+            if skipping or fn == "keepalive":
                 continue
             if fn == "side":        # fork: launch on the side stream, ordered after everything enqueued so far
                 if self._side is None:
@@ -524,9 +532,76 @@ class Flux:
                 fn, args = args
                 rc = fn(*args, self._side.cuda_stream)
             elif fn == "join":
-                cur.wait_stream(self._side)
+                if not skip_mod:
+                    cur.wait_stream(self._side)
                 continue
             else:
                 rc = fn(*args, stream)
             if rc != 0:
                 raise FluxHipError(f"{fn.__name__} failed with code {rc}")
+
+    def modulation_tables(self, timesteps, y: torch.Tensor, guidance: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The modulation tables (every Modulation.lin(silu(vec)) and the LastLayer adaLN, flux/layers.py:134-137,
+        298-300) of SEVERAL denoise steps at once: [n_steps, B, mod_rows].
+
+        vec = time_in(temb(t)) [+ guidance_in(temb(g))] + vector_in(y) (flux/model.py:113-120) does not depend on the
+        latents, so all steps' tables are known before the loop starts.  The 6.5 GB of modulation weights are then
+        streamed from HBM once per group of 4 / B steps instead of once per step (the GEMV kernel stays HBM-bound with
+        up to 4 activation rows in registers per weight row; its 16-row variant is VALU-bound), and the per-step forward
+        starts at the first block.  Every row is computed by the same kernel code with the same accumulation order as
+        the in-line launches of the plan, so the tables are bit-identical to what `__call__` computes step by step."""
+        lib = _lib.load()
+        P, D, NM = self.params, self.params.hidden_size, self.mod_rows
+        if P.guidance_embed and guidance is None:
+            raise ValueError("Didn't get guidance strength for guidance distilled model.")
+        B = y.shape[0]
+        ts = [float(t) for t in timesteps]
+        out = torch.empty(len(ts), B, NM, dtype=BF16, device=self.device)
+        if B > 16:
+            raise ValueError("modulation_tables: batch > 16 (use the in-line path)")
+        stream = torch.cuda.current_stream().cuda_stream
+        Wt = self._params
+        w = lambda n: Wt[n].data_ptr()                                  # noqa: E731
+        wo = lambda n: Wt[n].data_ptr() if n in Wt else None           # noqa: E731
+
+        def chk(rc, name):
+            if rc != 0:
+                raise FluxHipError(f"{name} failed with code {rc}")
+
+        per = max(1, 4 // B)                                            # steps per pass over the modulation weights
+        for k0 in range(0, len(ts), per):
+            n = min(per, len(ts) - k0)
+            R = n * B                                                   # row r = step (k0 + r // B), image r % B
+            tkey = (tuple(ts[k0:k0 + n]), B)
+            t_all = self._t_cache.get(tkey)          # schedules repeat from image to image: no host->device copy then
+            if t_all is None:
+                if len(self._t_cache) > 256:
+                    self._t_cache.clear()
+                t_all = torch.tensor(tkey[0], dtype=torch.float32, device=self.device).to(BF16).repeat_interleave(B).contiguous()
+                self._t_cache[tkey] = t_all
+            y_all = y.to(BF16).repeat(n, 1).contiguous()
+            temb = torch.empty(R, 256, dtype=BF16, device=self.device)
+            h1 = torch.empty(R, D, dtype=BF16, device=self.device)
+            vec = torch.empty(R, D, dtype=BF16, device=self.device)
+
+            def small(x, wn, o, K, N, silu_in, accum):
+                chk(lib.fluxhip_small_linear_bf16(x.data_ptr(), w(wn + ".weight"), wo(wn + ".bias"), o.data_ptr(), R, N, K,
+                                                  silu_in, accum, stream), "fluxhip_small_linear_bf16")
+
+            chk(lib.fluxhip_timestep_embedding_bf16(t_all.data_ptr(), temb.data_ptr(), R, 256, 1000.0, 10000.0, stream),
+                "fluxhip_timestep_embedding_bf16")
+            small(temb, "time_in.in_layer", h1, 256, D, 0, 0)
+            small(h1, "time_in.out_layer", vec, D, D, 1, 0)
+            if P.guidance_embed:
+                g_all = guidance.to(BF16).repeat(n).contiguous()
+                chk(lib.fluxhip_timestep_embedding_bf16(g_all.data_ptr(), temb.data_ptr(), R, 256, 1000.0, 10000.0, stream),
+                    "fluxhip_timestep_embedding_bf16")
+                small(temb, "guidance_in.in_layer", h1, 256, D, 0, 0)
+                small(h1, "guidance_in.out_layer", vec, D, D, 1, 1)
+            small(y_all, "vector_in.in_layer", h1, P.vec_in_dim, D, 0, 0)
+            small(h1, "vector_in.out_layer", vec, D, D, 1, 1)
+            # silu(vec) once, outside the weight-streaming loop (in-line, one step: silu_in = 1 on the fly; same bits)
+            chk(lib.fluxhip_silu_bf16(vec.data_ptr(), h1.data_ptr(), R * D, stream), "fluxhip_silu_bf16")
+            chk(lib.fluxhip_small_linear_bf16(h1.data_ptr(), self.mod_w.data_ptr(), self.mod_b.data_ptr(),
+                                              out[k0:k0 + n].data_ptr(), R, NM, D, 0, 0, stream), "fluxhip_small_linear_bf16")
+        return out

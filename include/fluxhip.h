@@ -117,6 +117,10 @@ int fluxhip_conv2d_small(const void* x, const void* w, const void* bias, void* o
  * the row-concatenated weight. */
 int fluxhip_small_linear_bf16(const void* x, const void* W, const void* bias, void* out, int B,
                               int N, int K, int silu_in, int accum, void* stream);
+/* nn.silu on n bf16 values (Modulation: lin(silu(vec)), flux/layers.py:136) as its own launch — for a GEMV pass
+ * that serves several steps' vectors at once (then called with silu_in = 0 on this output); bit-identical to the
+ * on-the-fly silu_in = 1 of fluxhip_small_linear_bf16. */
+int fluxhip_silu_bf16(const void* x, void* out, int64_t n, void* stream);
 
 /* out = (1 + scale) * LayerNorm(x, eps, no affine) + shift over rows of width D (D % 8 == 0,
  * D <= 4096).  B batches of Tr rows; row (b,t) is read at x + b*x_bstride + t*D and written at

@@ -94,6 +94,33 @@ def test_denoise_loop_tiny(dev):
         assert rel_l2(x, ref[i]) < 2e-2, f"step {i}"
 
 
+@pytest.mark.parametrize("guidance,B,steps", [(True, 1, 5), (False, 3, 4), (True, 2, 11)])
+def test_modulation_tables_match_inline(dev, guidance, B, steps):
+    """Flux.modulation_tables (all steps' Modulation.lin outputs in one pass over the modulation weights, grouped
+    <= 16 / B steps per pass) is BIT-identical to the table each in-line forward computes for its own timestep, and a
+    forward that skips its vec / modulation launches and reads that table gives a bit-identical prediction."""
+    from flux_generator_amd.flux.sampler import FluxSampler
+    OP, W, model = build(tiny_params(guidance, depth=4, singles=2), dev)
+    S, h, w = 24, 8, 12
+    img, img_ids, txt, txt_ids, vec = [t.to(dev) for t in make_inputs(OP, B, S, h, w, seed=7)]
+    ts = FluxSampler("flux-dev" if guidance else "flux-schnell").timesteps(steps, img.shape[1])[:steps]
+    gd = torch.full((B,), 3.5, dtype=BF, device=dev) if guidance else None
+    tabs = model.modulation_tables(ts, vec, gd)
+    assert tabs.shape == (steps, B, model.mod_rows)
+    ws = model._workspace(B, S, img.shape[1])
+    for i, t in enumerate(ts):
+        tt = torch.full((B,), t, dtype=BF, device=dev)
+        pred = model(img, img_ids, txt, txt_ids, tt, vec, gd)                  # in-line: computes ws["mods"] itself
+        assert torch.equal(ws["mods"], tabs[i]), f"step {i}"
+        ws["mods"].copy_(tabs[i])
+        ws["pred"].zero_()
+        model.run_plan(ws, skip_mod=True)
+        assert torch.equal(ws["pred"], pred), f"step {i}"
+    if guidance:
+        with pytest.raises(ValueError):
+            model.modulation_tables(ts, vec, None)
+
+
 def test_full_width_blocks(dev):
     """One double + one single block at Flux's real width (3072 = 24 x 128, MLP 12288), T = 320."""
     OP, W, model = build(dict(in_channels=64, vec_in_dim=768, context_in_dim=4096, hidden_size=3072, mlp_ratio=4.0,
