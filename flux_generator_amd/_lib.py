@@ -103,9 +103,11 @@ SIGNATURES = {
     "fluxhip_join_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "fluxhip_gemm_x3": (c_int, [C.POINTER(GemmX3Desc), c_void_p]),
     "fluxhip_conv2d_x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64]
-                          + [c_int] * 9 + [c_void_p, c_void_p]),
+                          + [c_int] * 9 + [c_void_p, c_int64, C.POINTER(c_int), c_void_p, c_void_p]),
     "fluxhip_conv_up2x_x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64]
-                             + [c_int] * 5 + [c_void_p, c_void_p]),
+                             + [c_int] * 5 + [c_void_p, c_int64, C.POINTER(c_int), c_void_p, c_void_p]),
+    "fluxhip_groupnorm_apply_x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64] + [c_int] * 4
+                                   + [c_float, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "fluxhip_groupnorm_silu_x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64] + [c_int] * 4
                                   + [c_float, c_int, c_void_p, c_int64, c_void_p]),
     "fluxhip_softmax_rows_x3": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_void_p]),
@@ -140,7 +142,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fluxhip_abi_version() != 2:
+    if lib.fluxhip_abi_version() != 3:
         raise RuntimeError("libfluxhip ABI version mismatch")
     if lib.fluxhip_arch() != b"gfx950":
         raise RuntimeError("libfluxhip was not built for gfx950")

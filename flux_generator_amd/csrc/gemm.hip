@@ -13,13 +13,14 @@ struct TileCfg {
   void (*dense_x3)(const GemmParams);   // FLAG_SPLIT (bf16x3, fp32-faithful) instantiations; null for most tiles
   void (*conv_x3)(const GemmParams);
   void (*dense_f8)(const GemmParams);   // FLAG_FP8 (e4m3 x e4m3 on the 16x16x128 block-scaled MFMA); simple-ring and ping-pong tiles
+  int wm = 1;                           // waves along M (rows per wave = bm / wm)
 };
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE, int FLAGS = 0>
 constexpr TileCfg make_cfg() {
   return TileCfg{BM, BN, WM * WN * 64, (NSTAGE * BM + (PIPE >= 3 ? NSTAGE + 1 : NSTAGE) * BN) * 64 * 2,
                  gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAGS>,
-                 gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE, FLAGS>, nullptr, nullptr, nullptr};
+                 gemm_nt_kernel<BM, BN, WM, WN, 1, NSTAGE, PIPE, FLAGS>, nullptr, nullptr, nullptr, WM};
 }
 // the same tile with the fp32-faithful (FLAG_SPLIT) kernels as well: only the tiles the VAE decoders use
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
@@ -44,7 +45,7 @@ constexpr TileCfg make_cfg_x3_f8() {
 
 // index 0 is unused ("auto")
 const TileCfg kCfgs[] = {
-    TileCfg{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr},
+    TileCfg{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
     make_cfg_f8<128, 128, 2, 2, 2, 0>(),  // 1: 64 KiB LDS, 2 blocks/CU
     make_cfg_f8<128, 64, 2, 2, 2, 0>(),   // 2: more blocks for N=3072 outputs at small M
     make_cfg_f8<64, 128, 2, 2, 2, 0>(),   // 3
@@ -255,6 +256,23 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 
+// Arms the GroupNorm-statistics output of a FLAG_SPLIT conv launch (GemmParams::gn_ws) when the chosen tile allows it:
+// the per-image pixel count of the GEMM's M space must be a multiple of the tile height and the workspace must hold
+// [B][nchunks][N][2] partials plus the [B][64][2] statistics gn_finalize appends.  Returns the chunk count (0 = not armed:
+// the consumer computes the partials itself).
+int arm_gn_stats(GemmParams& p, int cfg_code, int B, int hw, int parities, void* gn_ws, int64_t gn_ws_bytes) {
+  if (!gn_ws) return 0;
+  const TileCfg& c = kCfgs[cfg_code & 0xff];
+  const int wtm = c.bm / c.wm;
+  if (hw % c.bm || p.N % 4) return 0;
+  const int nchunks = parities * (hw / wtm);
+  if (((int64_t)B * nchunks * p.N + (int64_t)B * 64) * 2 * (int64_t)sizeof(float) > gn_ws_bytes) return 0;
+  p.gn_ws = (float*)gn_ws;
+  p.gn_hw = hw;
+  p.gn_nchunks = nchunks;
+  return nchunks;
+}
+
 }  // namespace
 
 // fluxhip_gemm_desc -> GemmParams (shared by the bf16 and the fp8 entry points); kalign = K granularity
@@ -439,8 +457,10 @@ extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bia
 extern "C" int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int64_t w_lo, const void* bias,
                                  const void* res, int64_t res_lo, void* out, int64_t out_lo, int B, int Hs,
                                  int Ws, int Cin, int Cout, int ksize, int stride, int pad, int ups,
-                                 const void* zero16, void* stream) {
-  if (!x || !w || !out || !zero16) return FLUXHIP_EINVAL;
+                                 void* gn_ws, int64_t gn_ws_bytes, int* gn_nchunks, const void* zero16,
+                                 void* stream) {
+  if (gn_nchunks) *gn_nchunks = 0;
+  if (!x || !w || !out || !zero16 || (gn_ws && !gn_nchunks)) return FLUXHIP_EINVAL;
   if (Cin % 64 || Cout % 4 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
     return FLUXHIP_EINVAL;
   if ((x_lo | w_lo) % 8 || (out_lo | res_lo) % 4) return FLUXHIP_EINVAL;
@@ -473,6 +493,7 @@ extern "C" int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int
   p.res_lo = res_lo;
   static const int forced = [] { const char* e = getenv("FLUXHIP_CONV_X3_CFG"); return e ? atoi(e) : 0; }();   // tuning knob
   int cfg = forced > 0 ? forced : pick_cfg(&t.M, 1, 1, Cout, p.K, true, true);
+  if (gn_ws) *gn_nchunks = arm_gn_stats(p, cfg, B, Ho * Wo, 1, gn_ws, gn_ws_bytes);
   return launch(p, cfg, true, (hipStream_t)stream, true);
 }
 
@@ -483,8 +504,10 @@ extern "C" int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int
 // float32 rounding of the pre-summed weights.
 extern "C" int fluxhip_conv_up2x_x3(const void* x, int64_t x_lo, const void* w4, int64_t w_lo, const void* bias,
                                     void* out, int64_t out_lo, int B, int Hs, int Ws, int Cin, int Cout,
-                                    const void* zero16, void* stream) {
-  if (!x || !w4 || !out || !zero16) return FLUXHIP_EINVAL;
+                                    void* gn_ws, int64_t gn_ws_bytes, int* gn_nchunks, const void* zero16,
+                                    void* stream) {
+  if (gn_nchunks) *gn_nchunks = 0;
+  if (!x || !w4 || !out || !zero16 || (gn_ws && !gn_nchunks)) return FLUXHIP_EINVAL;
   if (Cin % 64 || Cout % 4 || (x_lo | w_lo) % 8 || out_lo % 4) return FLUXHIP_EINVAL;
   static const int forced = [] { const char* e = getenv("FLUXHIP_CONV_X3_CFG"); return e ? atoi(e) : 0; }();
   GemmParams p{};
@@ -512,5 +535,6 @@ extern "C" int fluxhip_conv_up2x_x3(const void* x, int64_t x_lo, const void* w4,
   p.w_lo = w_lo;
   p.c_lo = out_lo;
   int cfg = forced > 0 ? forced : pick_cfg(&t.M, 1, 4, Cout, p.K, true, true);
+  if (gn_ws) *gn_nchunks = arm_gn_stats(p, cfg, B, Hs * Ws, 4, gn_ws, gn_ws_bytes);
   return launch(p, cfg, true, (hipStream_t)stream, true);
 }

@@ -99,6 +99,13 @@ struct GemmParams {
   // of bf16 planes (hi = bf16(x), lo = bf16(x - hi)); the lo plane sits `*_lo` ELEMENTS after the hi pointer.
   // bias is float32.  See the FLAG_SPLIT note at the kernel.
   long long a_lo, w_lo, c_lo, res_lo;
+  // FLAG_SPLIT convs only: GroupNorm statistics of the OUTPUT produced by the epilogue (the consumer of every VAE
+  // conv is a GroupNorm): per wave row-block and channel quad, (sum, sum of squares) of the float32 results, written
+  // in the per-channel partial layout gn_finalize_kernel reads ([image][chunk][C][2], the quad's sums on its first
+  // channel, zeros on the other three).  gn_hw = output pixels per image of the GEMM's M space (a multiple of BM, so
+  // a tile never straddles two images); chunk = parity * gn_hw / WTM + row-block (parity: sub-pixel convs).
+  float* gn_ws;
+  int gn_hw, gn_nchunks;
   // FLAG_FP8 kernels only: per-row dequantisation scales of the fp8 (e4m3fn) operands, per group:
   // C = (acc * a_scale[m] * w_scale[n]) + bias.  a_scale is indexed like the rows of A ([nbatch][M], batch stride
   // a_sc_bstride), w_scale like the rows of W ([N]).
@@ -879,6 +886,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
     // layout (8 bytes per lane and plane): the 3-pass main loop is three times as long as the bf16 one, so the
     // store tail weighs a third of what it does there.
     const float* fbias = (const float*)gBias;
+    float gs[NJ], gq[NJ];                          // GroupNorm partials of this lane's column quads (p.gn_ws)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) gs[j] = gq[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * WTM + i * 16 + r16;
@@ -917,6 +927,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
         ol[1] = pack_bf16x2(v[2] - bf_lo(oh[1]), v[3] - bf_hi(oh[1]));
         *(u32x2*)(gC + idx) = oh;
         *(u32x2*)(gC + idx + p.c_lo) = ol;
+        gs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+        gq[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+    }
+    if (AMODE == 1 && p.gn_ws) {
+      // reduce over the 16 rows a 16-lane group holds (and the MI row blocks summed above): fixed order, deterministic
+      const int img = m0 / p.gn_hw;
+      const int rb = (m0 - img * p.gn_hw) / WTM + wm + (p.cv.sub2 ? b * (p.gn_hw / WTM) : 0);
+      float* dst = p.gn_ws + (((long long)img * p.gn_nchunks + rb) * N) * 2;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float s_ = gs[j], q_ = gq[j];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+          s_ += __shfl_xor(s_, d, 64);
+          q_ += __shfl_xor(q_, d, 64);
+        }
+        const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
+        if (r16 == 0 && n4 < N) {
+          *(f32x4*)(dst + (long long)n4 * 2) = f32x4{s_, q_, 0.f, 0.f};
+          *(f32x4*)(dst + (long long)n4 * 2 + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
     return;

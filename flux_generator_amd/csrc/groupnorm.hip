@@ -136,13 +136,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ beta,
                                                        bf16_t* __restrict__ out, int HW, int C, int G,
                                                        int nchunks, int silu, int ppb, long long x_lo = 0,
-                                                       long long out_lo = 0) {
+                                                       long long out_lo = 0, int stat_chunks = 0) {
   constexpr int ROWS = 256 / CB;
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x;
   if (tid < G) {
-    const float* st = ws + ((long long)gridDim.y * nchunks * C + (long long)b * G + tid) * 2;
+    // the statistics follow the partial table, whose chunk count differs from this kernel's pixel partition when
+    // the partials came out of the producing conv's epilogue (stat_chunks)
+    const float* st = ws + ((long long)gridDim.y * (stat_chunks ? stat_chunks : nchunks) * C + (long long)b * G + tid) * 2;
     s_mean[tid] = st[0];
     s_rstd[tid] = st[1];
   }
@@ -272,5 +274,36 @@ extern "C" int fluxhip_groupnorm_silu_x3(const void* x, int64_t x_lo, const void
   else if (cb == 16) GN_RUN3(16);
   else GN_RUN3(8);
 #undef GN_RUN3
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+// GroupNorm [+ SiLU] of a split tensor whose per-channel partial sums already sit in `ws` ([B][nchunks][C][2] floats,
+// written by the epilogue of the conv that produced x: fluxhip_conv2d_x3 / fluxhip_conv_up2x_x3 with gn_ws): only the
+// finalize and apply launches run, and x is read once instead of twice.
+extern "C" int fluxhip_groupnorm_apply_x3(const void* x, int64_t x_lo, const void* gamma, const void* beta,
+                                          void* out, int64_t out_lo, int B, int HW, int C, int G, float eps,
+                                          int silu, void* ws, int64_t ws_bytes, int nchunks, void* stream) {
+  if (!x || !gamma || !beta || !out || !ws || nchunks < 1) return FLUXHIP_EINVAL;
+  if (B < 1 || HW < 1 || C % 8 || G < 1 || G > 64 || C % G || (x_lo | out_lo) % 8) return FLUXHIP_EINVAL;
+  const int cpr = C / 8;
+  const int cb = cpr % 64 == 0 ? 64 : cpr % 32 == 0 ? 32 : cpr % 16 == 0 ? 16 : cpr % 8 == 0 ? 8 : 0;
+  if (!cb) return FLUXHIP_EINVAL;
+  if (ws_bytes < ((int64_t)B * nchunks * C + (int64_t)B * G) * 2 * (int64_t)sizeof(float)) return FLUXHIP_EINVAL;
+  int ppb = 1024;
+  while (ppb > 32 && (long long)B * ((HW + ppb - 1) / ppb) * (cpr / cb) < 512) ppb >>= 1;
+  const int achunks = (HW + ppb - 1) / ppb;       // pixel partition of the apply pass (independent of the partial table)
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(achunks, B, cpr / cb), block(256);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(256), 0, s, (float*)ws, B, C, G, nchunks,
+                     (float)HW * (float)(C / G), eps);
+#define GN_APPLY3(CB)                                                                                \
+  hipLaunchKernelGGL((gn_apply_kernel<CB, true>), grid, block, 0, s, (const bf16_t*)x, (const float*)ws, \
+                     (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)out, HW, C, G, achunks, silu, ppb, \
+                     (long long)x_lo, (long long)out_lo, nchunks)
+  if (cb == 64) GN_APPLY3(64);
+  else if (cb == 32) GN_APPLY3(32);
+  else if (cb == 16) GN_APPLY3(16);
+  else GN_APPLY3(8);
+#undef GN_APPLY3
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }

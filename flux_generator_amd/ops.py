@@ -5,6 +5,7 @@ hand-written gfx950 kernel launched through ctypes.  All tensors must be CUDA(HI
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Sequence
 
 import torch
@@ -377,9 +378,16 @@ def linear_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], res: 
     return out
 
 
+def _gn_scratch(B: int, hw: int, parities: int, C: int, device) -> torch.Tensor:
+    """float32 scratch for the GroupNorm partials a conv epilogue emits: worst case 32-row wave tiles."""
+    return torch.empty((B * parities * ((hw + 31) // 32) * C + B * 64) * 2, dtype=torch.float32, device=device)
+
+
 def conv2d_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], stride: int = 1, pad: int = 1, ups: bool = False,
-              res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """NHWC conv in float32 on split tensors: x [2,B,H,W,Cin], w [2,Cout,kh,kw,Cin] (or [2,Cout,Cin]), b float32."""
+              res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, gn_stats: bool = False) -> torch.Tensor:
+    """NHWC conv in float32 on split tensors: x [2,B,H,W,Cin], w [2,Cout,kh,kw,Cin] (or [2,Cout,Cin]), b float32.
+    gn_stats: the epilogue also emits the GroupNorm partial sums of the output; they ride on the returned tensor
+    (`out._gn = (scratch, nchunks)`) and groupnorm_silu_x3 picks them up instead of reading the tensor a second time."""
     _split_ok(x, "x"); _split_ok(w, "w")
     _, B, Hs, Ws, Cin = x.shape
     Cout = w.shape[1]
@@ -392,10 +400,18 @@ def conv2d_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], strid
         out = torch.empty(2, B, Ho, Wo, Cout, dtype=BF16, device=x.device)
     if res is not None:
         _split_ok(res, "res")
+    if hasattr(out, "_gn"):
+        del out._gn                      # a reused output tensor must not keep the statistics of its previous contents
+    gws = _gn_scratch(B, Ho * Wo, 1, Cout, x.device) if gn_stats else None
+    nck = ctypes.c_int(0)
     _check(_lib.load().fluxhip_conv2d_x3(_p(x[0]), x.stride(0), _p(w[0]), w.stride(0), _p(_f32c(b, "bias")),
                                          _p(res[0]) if res is not None else None, res.stride(0) if res is not None else 0,
                                          _p(out[0]), out.stride(0), B, Hs, Ws, Cin, Cout, ks, stride, pad, int(ups),
+                                         _p(gws) if gn_stats else None, gws.numel() * 4 if gn_stats else 0,
+                                         ctypes.byref(nck) if gn_stats else None,
                                          _p(_zeros16(x.device)), _stream()), "fluxhip_conv2d_x3")
+    if nck.value > 0:
+        out._gn = (gws, nck.value)
     return out
 
 
@@ -414,7 +430,8 @@ def subpixel_weights(w: torch.Tensor) -> torch.Tensor:
     return torch.stack(par, 0).contiguous()
 
 
-def conv_up2x_x3(x: torch.Tensor, w4: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def conv_up2x_x3(x: torch.Tensor, w4: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+                 gn_stats: bool = False) -> torch.Tensor:
     """Upsample (nearest x2) + 3x3 conv in float32 as four 2x2 convs of the low-res split tensor x [2,B,H,W,Cin];
     w4 = split_f32(subpixel_weights(w)) = [2,4,Cout,2,2,Cin]."""
     _split_ok(x, "x"); _split_ok(w4, "w4")
@@ -424,9 +441,17 @@ def conv_up2x_x3(x: torch.Tensor, w4: torch.Tensor, b: Optional[torch.Tensor], o
     Cout = w4.shape[2]
     if out is None:
         out = torch.empty(2, B, Hs * 2, Ws * 2, Cout, dtype=BF16, device=x.device)
+    if hasattr(out, "_gn"):
+        del out._gn
+    gws = _gn_scratch(B, Hs * Ws, 4, Cout, x.device) if gn_stats else None
+    nck = ctypes.c_int(0)
     _check(_lib.load().fluxhip_conv_up2x_x3(_p(x[0]), x.stride(0), _p(w4[0]), w4.stride(0), _p(_f32c(b, "bias")),
                                             _p(out[0]), out.stride(0), B, Hs, Ws, Cin, Cout,
+                                            _p(gws) if gn_stats else None, gws.numel() * 4 if gn_stats else 0,
+                                            ctypes.byref(nck) if gn_stats else None,
                                             _p(_zeros16(x.device)), _stream()), "fluxhip_conv_up2x_x3")
+    if nck.value > 0:
+        out._gn = (gws, nck.value)
     return out
 
 
@@ -436,6 +461,13 @@ def groupnorm_silu_x3(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
     _, B, H, W_, Cc = x.shape
     if out is None:
         out = torch.empty_like(x)
+    st = getattr(x, "_gn", None)
+    if st is not None:       # partial sums left by the epilogue of the conv that produced x: finalize + apply only
+        gws, nck = st
+        _check(_lib.load().fluxhip_groupnorm_apply_x3(_p(x[0]), x.stride(0), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")),
+                                                      _p(out[0]), out.stride(0), B, H * W_, Cc, groups, eps, int(silu),
+                                                      _p(gws), gws.numel() * 4, nck, _stream()), "fluxhip_groupnorm_apply_x3")
+        return out
     ws = _gn_ws.get(x.device)
     need = (B * ((H * W_ + 31) // 32) * Cc + B * groups) * 2 * 4
     if ws is None or ws.numel() * 4 < need:

@@ -97,11 +97,12 @@ def resnet(P: ParamStore, fp32: bool, p: str, x: torch.Tensor, shortcut: str, gr
     if fp32:
         W3, F = (lambda n: P.get(n, "x3")), (lambda n: P.get(n, "f32"))     # noqa: E731
         h = ops.groupnorm_silu_x3(x, F(f"{p}.norm1.weight"), F(f"{p}.norm1.bias"), groups, eps, True)
-        h = ops.conv2d_x3(h, W3(f"{p}.conv1.weight"), F(f"{p}.conv1.bias"))
+        # every 3x3 conv output of the decoders feeds a GroupNorm next: its epilogue leaves the partial sums (gn_stats)
+        h = ops.conv2d_x3(h, W3(f"{p}.conv1.weight"), F(f"{p}.conv1.bias"), gn_stats=True)
         h = ops.groupnorm_silu_x3(h, F(f"{p}.norm2.weight"), F(f"{p}.norm2.bias"), groups, eps, True)
         if f"{p}.{shortcut}.weight" in P:
             x = ops.conv2d_x3(x, W3(f"{p}.{shortcut}.weight"), F(f"{p}.{shortcut}.bias"))
-        return ops.conv2d_x3(h, W3(f"{p}.conv2.weight"), F(f"{p}.conv2.bias"), res=x)
+        return ops.conv2d_x3(h, W3(f"{p}.conv2.weight"), F(f"{p}.conv2.bias"), res=x, gn_stats=True)
     W = lambda n: P.get(n, "bf16")     # noqa: E731
     h = ops.groupnorm_silu(x, W(f"{p}.norm1.weight"), W(f"{p}.norm1.bias"), groups, eps, True)
     h = ops.conv2d(h, W(f"{p}.conv1.weight"), W(f"{p}.conv1.bias"))
@@ -165,9 +166,9 @@ def attention(P: ParamStore, fp32: bool, p: str, x: torch.Tensor, norm: str, q: 
 
 def conv(P: ParamStore, fp32: bool, p: str, x: torch.Tensor, ups: bool = False) -> torch.Tensor:
     if fp32 and ups:     # Upsample + conv as four 2x2 convs of the low-res input (4/9 of the MFMA work)
-        return ops.conv_up2x_x3(x, P.get(f"{p}.weight", "x3up"), P.get(f"{p}.bias", "f32"))
+        return ops.conv_up2x_x3(x, P.get(f"{p}.weight", "x3up"), P.get(f"{p}.bias", "f32"), gn_stats=True)
     if fp32:
-        return ops.conv2d_x3(x, P.get(f"{p}.weight", "x3"), P.get(f"{p}.bias", "f32"), ups=ups)
+        return ops.conv2d_x3(x, P.get(f"{p}.weight", "x3"), P.get(f"{p}.bias", "f32"), ups=ups, gn_stats=True)
     return ops.conv2d(x, P.get(f"{p}.weight", "bf16"), P.get(f"{p}.bias", "bf16"), ups=ups)
 
 

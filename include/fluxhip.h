@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define FLUXHIP_ABI_VERSION 2
+#define FLUXHIP_ABI_VERSION 3
 
 int fluxhip_abi_version(void);
 /* "gfx950" — the only architecture this library is built for. */
@@ -256,22 +256,32 @@ typedef struct fluxhip_gemm_x3_desc {
  * single-head attention, :49; vae.py:25-42). */
 int fluxhip_gemm_x3(const fluxhip_gemm_x3_desc* d, void* stream);
 /* nn.Conv2d in float32 (same geometry rules as fluxhip_conv2d_bf16; res != NULL adds the split residual). */
+/* gn_ws != NULL (gn_ws_bytes of float32 scratch, gn_nchunks != NULL): the epilogue also writes the GroupNorm
+ * partial sums of the OUTPUT (every VAE conv feeds a GroupNorm) as [B][*gn_nchunks][Cout][2] floats, to be consumed by
+ * fluxhip_groupnorm_apply_x3 — the statistics pass over the tensor disappears.  *gn_nchunks = 0 when the chosen tile
+ * cannot do it (pixels per image not a multiple of the tile height, or the scratch is too small): use
+ * fluxhip_groupnorm_silu_x3 then. */
 int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int64_t w_lo, const void* bias,
                       const void* res, int64_t res_lo, void* out, int64_t out_lo, int B, int Hs, int Ws,
-                      int Cin, int Cout, int ksize, int stride, int pad, int ups, const void* zero16,
-                      void* stream);
+                      int Cin, int Cout, int ksize, int stride, int pad, int ups, void* gn_ws,
+                      int64_t gn_ws_bytes, int* gn_nchunks, const void* zero16, void* stream);
 /* Upsample (nearest x2) + Conv2d 3x3 pad 1 in float32 (flux/autoencoder.py:117-122; stable_diffusion/vae.py
  * upsample path) in sub-pixel form: four 2x2 convs of the low-res input, one per output-pixel parity, on weights
  * w4 = [4][Cout][2][2][Cin] in which the 3x3 taps that read the same source pixel are pre-summed (parity =
  * 2*dy + dx; dy = 0: rows {w0, w1+w2}, dy = 1: rows {w0+w1, w2}; same along x).  4/9 of the MFMA work of the
  * fused-upsample loader.  x: split [B][Hs][Ws][Cin]; out: split [B][2Hs][2Ws][Cout]; bias float32. */
 int fluxhip_conv_up2x_x3(const void* x, int64_t x_lo, const void* w4, int64_t w_lo, const void* bias, void* out,
-                         int64_t out_lo, int B, int Hs, int Ws, int Cin, int Cout, const void* zero16,
-                         void* stream);
+                         int64_t out_lo, int B, int Hs, int Ws, int Cin, int Cout, void* gn_ws,
+                         int64_t gn_ws_bytes, int* gn_nchunks, const void* zero16, void* stream);
 /* GroupNorm [+ SiLU] on a split NHWC tensor with float32 gamma / beta; float32 arithmetic throughout. */
 int fluxhip_groupnorm_silu_x3(const void* x, int64_t x_lo, const void* gamma, const void* beta, void* out,
                               int64_t out_lo, int B, int HW, int C, int G, float eps, int silu, void* ws,
                               int64_t ws_bytes, void* stream);
+/* The same GroupNorm when the partial sums of x are already in ws (written by the producing conv's epilogue, see
+ * fluxhip_conv2d_x3): finalize + apply only. */
+int fluxhip_groupnorm_apply_x3(const void* x, int64_t x_lo, const void* gamma, const void* beta, void* out,
+                               int64_t out_lo, int B, int HW, int C, int G, float eps, int silu, void* ws,
+                               int64_t ws_bytes, int nchunks, void* stream);
 /* softmax(scale * S) of float32 logits -> split P. */
 int fluxhip_softmax_rows_x3(const void* s, void* p, int64_t p_lo, int64_t rows, int cols, int ld, float scale,
                             void* stream);

@@ -189,6 +189,41 @@ def test_conv_up2x_x3(dev, Cin, Cout, hw, B):
         ops.conv_up2x_x3(X, ops.split_f32(w.to(dev)), b.to(dev))
 
 
+@pytest.mark.parametrize("Cin,Cout,hw,B,ups", [(128, 128, (32, 32), 2, False), (512, 256, (16, 16), 1, False), (256, 256, (16, 32), 2, True),
+                                                (64, 512, (64, 64), 1, False), (128, 128, (13, 7), 2, False), (128, 64, (5, 5), 1, True)])
+def test_groupnorm_stats_from_conv_epilogue(dev, Cin, Cout, hw, B, ups):
+    """The GroupNorm partial sums a conv epilogue leaves (gn_stats) give the same normalisation as the stand-alone
+    statistics pass over the stored tensor, and as float64; shapes whose pixel count is not a multiple of the tile
+    height fall back to the stand-alone pass by themselves."""
+    from flux_generator_amd import ops
+    x, w, b = frnd(B, *hw, Cin, seed=1), frnd(Cout, 3, 3, Cin, seed=2, scale=(9 * Cin) ** -0.5), frnd(Cout, seed=3, scale=3.0)
+    g, be = frnd(Cout, seed=4) + 1.5, frnd(Cout, seed=5)
+    res = None
+    X = ops.split_f32(x.to(dev))
+    if ups:
+        y = ops.conv_up2x_x3(X, ops.split_f32(ops.subpixel_weights(w.to(dev))), b.to(dev), gn_stats=True)
+        ref = O.conv2d(O.upsample_nearest2(x).double(), w.double(), b.double())
+    else:
+        res = frnd(B, *hw, Cout, seed=6)
+        y = ops.conv2d_x3(X, ops.split_f32(w.to(dev)), b.to(dev), res=ops.split_f32(res.to(dev)), gn_stats=True)
+        ref = O.conv2d(x.double(), w.double(), b.double()) + res.double()
+    px = hw[0] * hw[1] * (4 if ups else 1)
+    fused = hasattr(y, "_gn")
+    assert fused == ((hw[0] * hw[1]) % 256 == 0), "which shapes arm the epilogue statistics"
+    got = ops.join_f32(ops.groupnorm_silu_x3(y, g.to(dev), be.to(dev), 32, 1e-6, True))
+    plain = y.clone()                                  # same values, no statistics attached: stand-alone pass
+    assert not hasattr(plain, "_gn")
+    alone = ops.join_f32(ops.groupnorm_silu_x3(plain, g.to(dev), be.to(dev), 32, 1e-6, True))
+    want = O.silu(O.group_norm(ref, g.double(), be.double(), 32, 1e-6)).float()
+    e1, e2 = rel_l2(got, want), rel_l2(alone, want)
+    print(f"GN after conv {Cin}->{Cout} {hw} ups={ups}: fused={fused} rel-L2 {e1:.2e} (stand-alone {e2:.2e}), {px} px")
+    assert e1 < X3 and e2 < X3 and float((got - alone).abs().max()) < 2e-5 * float(alone.abs().max())
+    if fused:      # a reused output tensor drops the statistics of its previous contents
+        ops.conv2d_x3(X, ops.split_f32(w.to(dev)), b.to(dev), out=y) if not ups else ops.conv_up2x_x3(
+            X, ops.split_f32(ops.subpixel_weights(w.to(dev))), b.to(dev), out=y)
+        assert not hasattr(y, "_gn")
+
+
 @pytest.mark.parametrize("C,hw", [(512, (16, 16)), (256, (24, 40)), (128, (64, 64))])
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm_x3(dev, C, hw, silu):
