@@ -101,8 +101,8 @@ struct GemmParams {
   long long a_lo, w_lo, c_lo, res_lo;
   // FLAG_SPLIT convs only: GroupNorm statistics of the OUTPUT produced by the epilogue (the consumer of every VAE
   // conv is a GroupNorm): per wave row-block and channel quad, (sum, sum of squares) of the float32 results, written
-  // in the per-channel partial layout gn_finalize_kernel reads ([image][chunk][C][2], the quad's sums on its first
-  // channel, zeros on the other three).  gn_hw = output pixels per image of the GEMM's M space (a multiple of BM, so
+  // in the per-channel partial layout gn_finalize_kernel reads ([image][chunk][C][2]) on the quad's FIRST channel only
+  // (the other three slots are never written nor read: gn_finalize_kernel's channel step is 4 for these tables).  gn_hw = output pixels per image of the GEMM's M space (a multiple of BM, so
   // a tile never straddles two images); chunk = parity * gn_hw / WTM + row-block (parity: sub-pixel convs).
   float* gn_ws;
   int gn_hw, gn_nchunks;
@@ -945,10 +945,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
           q_ += __shfl_xor(q_, d, 64);
         }
         const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
-        if (r16 == 0 && n4 < N) {
-          *(f32x4*)(dst + (long long)n4 * 2) = f32x4{s_, q_, 0.f, 0.f};
-          *(f32x4*)(dst + (long long)n4 * 2 + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        if (r16 == 0 && n4 < N) *(float2*)(dst + (long long)n4 * 2) = float2{s_, q_};
       }
     }
     return;

@@ -86,22 +86,24 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   }
 }
 
+// cstep: 1 = one partial per channel (gn_partial_kernel); 4 = one partial per aligned channel quad, stored on the quad's
+// first channel (the conv epilogue's tables, gemm_core.h GemmParams::gn_ws; needs (C / G) % 4 == 0)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(float* __restrict__ ws, int B, int C, int G,
-                                                          int nchunks, float cnt, float eps) {
+                                                          int nchunks, float cnt, float eps, int cstep = 1) {
   // one block per (batch, group); fixed thread -> item assignment and a fixed reduction tree: deterministic
   __shared__ float red[2][4];
   const int i = blockIdx.x, tid = threadIdx.x;
   const int b = i / G, g = i - b * G;
-  const int cg = C / G;
+  const int cg = C / G, cq = cg / cstep;
   float ts = 0.f, tq = 0.f;
-  const int items = nchunks * cg;
+  const int items = nchunks * cq;
   constexpr int U = 4;
   for (int k0 = tid; k0 < items; k0 += 256 * U) {
     float2 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = k0 + u * 256;
-      const int chunk = k / cg, c = g * cg + (k - chunk * cg);
+      const int chunk = k / cq, c = g * cg + (k - chunk * cq) * cstep;
       v[u] = k < items ? *(const float2*)(ws + (((long long)b * nchunks + chunk) * C + c) * 2) : float2{0.f, 0.f};
     }
 #pragma unroll
@@ -284,7 +286,7 @@ extern "C" int fluxhip_groupnorm_apply_x3(const void* x, int64_t x_lo, const voi
                                           void* out, int64_t out_lo, int B, int HW, int C, int G, float eps,
                                           int silu, void* ws, int64_t ws_bytes, int nchunks, void* stream) {
   if (!x || !gamma || !beta || !out || !ws || nchunks < 1) return FLUXHIP_EINVAL;
-  if (B < 1 || HW < 1 || C % 8 || G < 1 || G > 64 || C % G || (x_lo | out_lo) % 8) return FLUXHIP_EINVAL;
+  if (B < 1 || HW < 1 || C % 8 || G < 1 || G > 64 || C % G || (C / G) % 4 || (x_lo | out_lo) % 8) return FLUXHIP_EINVAL;
   const int cpr = C / 8;
   const int cb = cpr % 64 == 0 ? 64 : cpr % 32 == 0 ? 32 : cpr % 16 == 0 ? 16 : cpr % 8 == 0 ? 8 : 0;
   if (!cb) return FLUXHIP_EINVAL;
@@ -295,7 +297,7 @@ extern "C" int fluxhip_groupnorm_apply_x3(const void* x, int64_t x_lo, const voi
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(achunks, B, cpr / cb), block(256);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(256), 0, s, (float*)ws, B, C, G, nchunks,
-                     (float)HW * (float)(C / G), eps);
+                     (float)HW * (float)(C / G), eps, 4);
 #define GN_APPLY3(CB)                                                                                \
   hipLaunchKernelGGL((gn_apply_kernel<CB, true>), grid, block, 0, s, (const bf16_t*)x, (const float*)ws, \
                      (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)out, HW, C, G, achunks, silu, ppb, \

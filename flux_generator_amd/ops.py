@@ -462,7 +462,7 @@ def groupnorm_silu_x3(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
     if out is None:
         out = torch.empty_like(x)
     st = getattr(x, "_gn", None)
-    if st is not None:       # partial sums left by the epilogue of the conv that produced x: finalize + apply only
+    if st is not None and (Cc // groups) % 4 == 0:     # partial sums (per channel quad) left by the epilogue of the conv that produced x: finalize + apply only
         gws, nck = st
         _check(_lib.load().fluxhip_groupnorm_apply_x3(_p(x[0]), x.stride(0), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")),
                                                       _p(out[0]), out.stride(0), B, H * W_, Cc, groups, eps, int(silu),

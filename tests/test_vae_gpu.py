@@ -258,6 +258,22 @@ def test_small_ops_x3(dev):
     assert rel_l2(u[..., :16], z.float().cpu() / 0.3611 + 0.1159) < X3 and torch.count_nonzero(u[..., 16:]) == 0
 
 
+@pytest.mark.parametrize("Cin,Cout,hw,B", [(128, 3, (64, 64), 1), (128, 3, (70, 93), 2), (64, 4, (65, 64), 1), (256, 1, (64, 80), 1),
+                                           (512, 3, (72, 57), 1)])
+def test_conv_out_tiled_x3(dev, Cin, Cout, hw, B):
+    """conv_out (C -> <= 4 channels) on images large enough for the LDS-tiled kernel (>= 4096 pixels): ragged tile
+    edges, image borders, every channel count, clip epilogue; vs float64."""
+    from flux_generator_amd import ops
+    x, w, b = frnd(B, *hw, Cin, seed=4), frnd(Cout, 3, 3, Cin, seed=5, scale=(9 * Cin) ** -0.5), frnd(Cout, seed=6)
+    ref = O.conv2d(x.double(), w.double(), b.double()).float()
+    X = ops.split_f32(x.to(dev))
+    got = ops.conv2d_out_image_x3(X, w.to(dev), b.to(dev), False)
+    assert got.shape == ref.shape and rel_l2(got, ref) < X3
+    assert float((got.cpu() - ref).abs().max()) < 1e-4
+    assert rel_l2(ops.conv2d_out_image_x3(X, w.to(dev), b.to(dev), True), torch.clip(ref + 1, 0, 2) * 0.5) < X3
+    assert rel_l2(ops.conv2d_out_image_x3(X, w.to(dev), None, False), ref - b) < X3
+
+
 def _tiny_ae_f32(dev, seed=1):
     """float32 weights that are NOT bf16-representable, as in the reference's fp32 checkpoint."""
     from flux_generator_amd.flux.autoencoder import AutoEncoder, AutoEncoderParams
