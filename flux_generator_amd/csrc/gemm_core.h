@@ -938,12 +938,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
       float* dst = p.gn_ws + (((long long)img * p.gn_nchunks + rb) * N) * 2;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        float s_ = gs[j], q_ = gq[j];
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-          s_ += __shfl_xor(s_, d, 64);
-          q_ += __shfl_xor(q_, d, 64);
-        }
+        const float s_ = row16_sum(gs[j]), q_ = row16_sum(gq[j]);
         const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
         if (r16 == 0 && n4 < N) *(float2*)(dst + (long long)n4 * 2) = float2{s_, q_};
       }
