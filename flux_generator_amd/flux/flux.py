@@ -51,6 +51,7 @@ class FluxPipeline:
         self.t5_tokenizer = load_t5_tokenizer(name)
         self.sampler = FluxSampler(name)
         self._graphs = {}
+        self._graph_epoch = 0
 
     def ensure_models_are_loaded(self):
         torch.cuda.synchronize(self.device)
@@ -109,6 +110,9 @@ class FluxPipeline:
         skip_mod = mods is not None
         if skip_mod:
             ws["mods"].copy_(mods)
+        if self._graph_epoch != self.flow.plan_epoch:       # the flow model rebuilt its plans (enable_fp8): old graphs are stale
+            self._graphs = {k: v for k, v in self._graphs.items() if k[0] == "decode"}
+            self._graph_epoch = self.flow.plan_epoch
         key = (B, S, L, "premod") if skip_mod else (B, S, L)
         g = self._graphs.get(key)
         if g is None:

@@ -67,6 +67,7 @@ class Flux:
         self.device = _lib.bind_device(device)
         self._side = None            # side stream of the launch plan (modulation GEMV under the first blocks)
         self._t_cache = {}           # modulation_tables: device copies of the timestep groups seen so far
+        self.plan_epoch = 0          # bumped whenever the workspaces / launch plans are rebuilt (enable_fp8)
         _lib.load()
         self._alloc_parameters()
         self._ws: Dict[Tuple[int, int, int], dict] = {}
@@ -207,6 +208,7 @@ class Flux:
                     self._w8[name[: -len(".weight")]] = ops.quantize_rows_fp8(w)
         self.fp8 = bool(enabled)
         self._ws.clear()
+        self.plan_epoch += 1         # captured graphs of the old plans (FluxPipeline._graphs) must not be replayed
         return self
 
     def fuse_lora(self, adapter: Dict[str, torch.Tensor], scale: float = 1.0) -> int:
@@ -235,6 +237,8 @@ class Flux:
             ap[:, :r] = a.to(device=self.device, dtype=BF16)
             ops.gemm(make_gemm_desc([dict(A=bt.data_ptr(), W=ap.data_ptr(), C=W.data_ptr(), res=W.data_ptr(), M=out_d)],
                                     1, in_d, rp, rp, in_d, EPI_GATE_RES, alpha=float(scale)))
+            if n in self._w8:            # fp8 copy of this layer already made: requantise IN PLACE (launch plans hold its address)
+                ops.quantize_rows_fp8(W, out=self._w8[n][0], scale=self._w8[n][1])
         torch.cuda.synchronize(self.device)
         return len(names)
 

@@ -418,3 +418,49 @@ def test_lora_adapter_fuse(dev, tmp_path, monkeypatch):
     bad["single_blocks.9.linear1.lora_b"] = bad["single_blocks.1.linear1.lora_b"]
     with pytest.raises(ValueError):
         flow.fuse_lora(bad)
+
+
+def test_fp8_toggle_and_lora_after_first_generation(dev, monkeypatch):
+    """State changes AFTER a generation has captured its hipGraphs must not leave stale state behind:
+    (1) `flow.enable_fp8()` rebuilds the launch plans, so the pipeline drops the graphs captured over the old ones
+    (same latents as a pipeline that was fp8 from the start, bit for bit); (2) `fuse_lora` on an fp8 model requantises
+    the touched layers in place (same latents as fuse-then-quantise, the CLI's order)."""
+    import warnings
+    from flux_generator_amd.flux.flux import FluxPipeline
+    _tiny_flux_zoo(monkeypatch)
+
+    def make():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            p = FluxPipeline("flux-schnell", device=str(dev))
+        return p
+
+    def run(p):
+        lat = p.generate_latents("a photo of a cat", n_images=1, num_steps=3, latent_size=(16, 16), seed=7)
+        next(lat)
+        x = None
+        for x in lat:
+            pass
+        torch.cuda.synchronize()
+        return x.clone()
+
+    g = torch.Generator().manual_seed(3)
+    a = make()
+    x_bf16 = run(a)                              # captures the bf16 graphs
+    a.flow.enable_fp8()
+    x_late = run(a)
+    b = make()
+    b.flow.enable_fp8()
+    x_early = run(b)
+    assert torch.equal(x_late, x_early) and not torch.equal(x_late, x_bf16)
+    # LoRA after fp8 (requantise in place) == LoRA before fp8
+    n = "double_blocks.1.img_attn.qkv"
+    out_d, in_d = a.flow.parameters()[f"{n}.weight"].shape
+    adapter = {f"{n}.lora_a": (torch.randn(in_d, 8, generator=g) * in_d ** -0.5).to(BF),
+               f"{n}.lora_b": (torch.randn(8, out_d, generator=g) * 0.2).to(BF)}
+    assert a.flow.fuse_lora(adapter) == 1        # a: fp8 already on
+    c = make()
+    assert c.flow.fuse_lora(adapter) == 1        # c: fuse, then quantise
+    c.flow.enable_fp8()
+    x_a, x_c = run(a), run(c)
+    assert torch.equal(x_a, x_c) and not torch.equal(x_a, x_late)
