@@ -201,7 +201,7 @@ class FluxPipeline:
         precision = precision or self.ae.precision
         if not self.use_graph:
             return self.ae.decode_packed(x, latent_size, precision)
-        key = ("decode", x.shape[0], tuple(latent_size), precision)
+        key = ("decode", x.shape[0], tuple(latent_size), precision, self.ae._store.epoch)
         ent = self._graphs.get(key)
         if ent is None:
             static_in = x.to(self.dtype).contiguous().clone()

@@ -184,6 +184,9 @@ class Flux:
                 raise ValueError(f"Shape mismatch for {k}: expected {tuple(dst.shape)}, got {tuple(w.shape)}")
             dst.copy_(w.to(device=self.device, dtype=BF16))
             seen.add(k)
+            n = k[: -len(".weight")] if k.endswith(".weight") else None
+            if n in self._w8:            # an fp8 copy exists already: requantise in place (launch plans hold its address)
+                ops.quantize_rows_fp8(dst, out=self._w8[n][0], scale=self._w8[n][1])
         if strict:
             missing = set(self._params) - seen
             if missing:

@@ -134,7 +134,7 @@ class StableDiffusion:
         precision = precision or self.autoencoder.precision
         if not self.use_graph:
             return self.autoencoder.decode_image(x_t, precision)
-        key = ("decode", tuple(x_t.shape), precision)
+        key = ("decode", tuple(x_t.shape), precision, self.autoencoder._store.epoch)
         ent = self._graphs.get(key)
         if ent is None:
             sx = x_t.to(self.dtype).contiguous().clone()

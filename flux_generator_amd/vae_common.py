@@ -35,6 +35,7 @@ class ParamStore:
         self.master = {k: torch.empty(*shp, dtype=F32, device=device) for k, shp in shapes.items()}
         self._pad64 = set(pad64)         # weights whose last (input-channel) dim is zero-padded to a multiple of 64
         self._derived: Dict[Tuple[str, str], Tuple[int, torch.Tensor]] = {}
+        self.epoch = 0                   # bumped by load(): part of the pipelines' decode-graph keys
 
     def __contains__(self, name: str) -> bool:
         return name in self.master
@@ -53,6 +54,7 @@ class ParamStore:
     def load(self, weights: Union[Dict[str, torch.Tensor], Iterable[Tuple[str, torch.Tensor]]], strict: bool,
              skip_prefixes: Tuple[str, ...]) -> None:
         items = weights.items() if isinstance(weights, dict) else weights
+        self.epoch += 1           # derived layouts are rebuilt lazily: hipGraphs captured over the old ones are stale
         seen = set()
         for k, w in items:
             if k not in self.master:
