@@ -142,7 +142,13 @@ DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory
 // drain in steady state) and the barrier is a raw s_barrier, because __syncthreads() would drain
 // the in-flight LDS-DMA (cdna guide §5, "Pipelining across barriers").
 template <int BM, int BN, int WM, int WN, int AMODE, int NSTAGE, int PIPE, int FLAGS = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p) {
+// 8-wave tiles with more than half of the CU's LDS own the CU: two waves per SIMD is all they can ever have, so the
+// register allocator is told not to squeeze below 256 VGPRs for a third wave that can never be resident (it spilled
+// 9-25 dwords into scratch doing so on the conv variants).
+#define GEMM_OWNS_CU (WM * WN == 8 && (NSTAGE * BM + (PIPE >= 3 ? NSTAGE + 1 : NSTAGE) * BN) * 128 > 80 * 1024)
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(GEMM_OWNS_CU ? 2 : 1, GEMM_OWNS_CU ? 2 : 8)))
+void gemm_nt_kernel(const GemmParams p) {
+#undef GEMM_OWNS_CU
   constexpr int BK = 64;
   constexpr int NWAVES = WM * WN;
   constexpr bool PP = PIPE == 6;                   // ping-pong schedule
@@ -581,11 +587,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmParams p
               s_ = src[i] + (long long)ks * (BK * 2) + a_adj;
             } else if (!p.cv.ups) {
               const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj;
-              s_ = ((gyx[i] >> tap) & 1) ? cX + (long long)(int)gimg[i] * 16 + uoff : (const char*)p.cv.zero;
+              // opaque copy: otherwise hipcc hoists the loop-invariant 64-bit cX + img * 16 of every piece out of the
+              // K loop, spills the 8 pairs to scratch and reloads one per piece per stage - VMEM loads whose vmcnt(0)
+              // waits drain the LDS-DMA pieces in flight
+              uint32_t img = gimg[i];
+              asm volatile("" : "+v"(img));
+              s_ = ((gyx[i] >> tap) & 1) ? cX + (long long)(int)img * 16 + uoff : (const char*)p.cv.zero;
             } else {
               const int yy = (gyx[i] >> 16) + dy, xx = (int)(short)(gyx[i] & 0xffff) + dx;
               const bool ok = (yy >= 0) & (yy < p.cv.Hs * 2) & (xx >= 0) & (xx < p.cv.Ws * 2);
-              s_ = ok ? cX + (long long)gimg[i] * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2 + a_adj
+              uint32_t img = gimg[i];
+              asm volatile("" : "+v"(img));
+              s_ = ok ? cX + (long long)img * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2 + a_adj
                       : (const char*)p.cv.zero;
             }
             glds16(s_, smem + slot * A_BYTES + (lw + i * LW) * 1024);
