@@ -6,11 +6,11 @@ OUT=../lib
 mkdir -p "$OUT" build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
-SRCS="api gemm small_linear norm groupnorm attention elementwise unet_ops"
+SRCS="api gemm gemm_conv gemm_x3f8 small_linear norm groupnorm attention elementwise unet_ops"
 pids=()
 for s in $SRCS; do
   if [ ! -f build/$s.o ] || [ $s.hip -nt build/$s.o ] || [ common.h -nt build/$s.o ] || \
-     [ gemm_core.h -nt build/$s.o ] || [ ../../include/fluxhip.h -nt build/$s.o ]; then
+     [ gemm_core.h -nt build/$s.o ] || [ gemm_tiles.h -nt build/$s.o ] || [ ../../include/fluxhip.h -nt build/$s.o ]; then
     $HIPCC $FLAGS -c $s.hip -o build/$s.o &
     pids+=($!)
   fi

@@ -3,6 +3,20 @@
 #include <cmath>
 #include <cstdlib>
 #include "gemm_core.h"
+#include "gemm_tiles.h"
+
+// instantiated in gemm_conv.hip / gemm_x3f8.hip
+#define X(BM, BN, WM, WN, NS, PIPE, FL) extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 1, NS, PIPE, FL>(const GemmParams);
+FLUXHIP_TILES(X)
+#undef X
+#define X(BM, BN, WM, WN, NS, PIPE)                                                                           \
+  extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_SPLIT>(const GemmParams); \
+  extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 1, NS, PIPE, FLAG_SPLIT>(const GemmParams);
+FLUXHIP_TILES_X3(X)
+#undef X
+#define X(BM, BN, WM, WN, NS, PIPE) extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_FP8>(const GemmParams);
+FLUXHIP_TILES_F8(X)
+#undef X
 
 namespace {
 

@@ -1,0 +1,13 @@
+// Explicit instantiations of the fp32-faithful (FLAG_SPLIT, dense + conv) and fp8 (FLAG_FP8, dense) kernels: a
+// translation unit of its own (see gemm_tiles.h).
+#include "gemm_core.h"
+#include "gemm_tiles.h"
+
+#define X(BM, BN, WM, WN, NS, PIPE)                                                                    \
+  template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_SPLIT>(const GemmParams); \
+  template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 1, NS, PIPE, FLAG_SPLIT>(const GemmParams);
+FLUXHIP_TILES_X3(X)
+#undef X
+#define X(BM, BN, WM, WN, NS, PIPE) template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_FP8>(const GemmParams);
+FLUXHIP_TILES_F8(X)
+#undef X
