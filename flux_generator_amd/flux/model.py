@@ -292,7 +292,13 @@ class Flux:
         def call(fn, *args):
             plan.append((fn, args))
 
+        # diagnostic: FLUXHIP_PLAN_TILES="3072x12288=558,..." forces tile | split << 8 for the block GEMMs of that N x K
+        forced = {tuple(int(v) for v in e.split("=")[0].split("x")): int(e.split("=")[1])
+                  for e in os.environ.get("FLUXHIP_PLAN_TILES", "").split(",") if e}
+
         def gemm(groups, nbatch, N, K, lda, ldc, epi=EPI_BIAS, **kw):
+            if (N, K) in forced:
+                kw["tile_cfg"] = forced[(N, K)]
             d = make_gemm_desc(groups, nbatch, N, K, lda, ldc, epi, **kw)
             keep.append(d)
             call(lib.fluxhip_gemm_bf16, ctypes.byref(d))
