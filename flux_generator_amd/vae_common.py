@@ -88,6 +88,10 @@ class ParamStore:
         return d
 
 
+# Queries per block of the single-head VAE attention: the float32 logits buffer is ATTN_QUERY_BLOCK x N (64 MiB at
+# 512x512, 256 MiB at 1024x1024 where N x N would be 1 GiB per image), the softmax sees whole rows, so no online rescaling.
+ATTN_QUERY_BLOCK = 4096
+
 # ---------------------------------------------------------------------------------------------- blocks
 # `names` maps the role of a sub-module to the reference's attribute name in that decoder:
 #   Flux AE (flux/autoencoder.py):   shortcut "nin_shortcut", attention norm "norm", q/k/v/out "q","k","v","proj_out"
@@ -131,14 +135,17 @@ def attention(P: ParamStore, fp32: bool, p: str, x: torch.Tensor, norm: str, q: 
         out = torch.empty_like(xr)
         Np = (N + 63) // 64 * 64
         vt = torch.zeros(2, C, Np, dtype=BF16, device=dev)
-        s = torch.empty(N, Np, dtype=F32, device=dev)
-        pm = torch.zeros(2, N, Np, dtype=BF16, device=dev)
+        QB = min(N, ATTN_QUERY_BLOCK)            # logits exist for one block of queries at a time: QB x N, never N x N
+        s = torch.empty(QB, Np, dtype=F32, device=dev)
+        pm = torch.zeros(2, QB, Np, dtype=BF16, device=dev)       # padded key columns stay zero
         ob = torch.empty(2, N, C, dtype=BF16, device=dev)
         for b in range(B):
             ops.gemm_x3(W3(f"{p}.{v}.weight"), y[:, b], vt, C, N, C, C, Np, bias=F(f"{p}.{v}.bias"), row_bias=True)
-            ops.gemm_x3(qq[:, b], kk[:, b], s, N, N, C, C, Np, out_f32=True)
-            ops.softmax_rows_x3(s, C ** -0.5, pm, cols=N)
-            ops.gemm_x3(pm, vt, ob, N, C, Np, Np, C)
+            for r0 in range(0, N, QB):
+                m = min(QB, N - r0)
+                ops.gemm_x3(qq[:, b, r0:r0 + m], kk[:, b], s, m, N, C, C, Np, out_f32=True)
+                ops.softmax_rows_x3(s[:m], C ** -0.5, pm[:, :m], cols=N)
+                ops.gemm_x3(pm[:, :m], vt, ob[:, r0:r0 + m], m, C, Np, Np, C)
             ops.gemm_x3(ob, W3(f"{p}.{o}.weight"), out[:, b], N, C, C, C, C, bias=F(f"{p}.{o}.bias"), res=xr[:, b])
         return out.view(2, B, H, Wd, C)
     W = lambda n: P.get(n, "bf16")     # noqa: E731
@@ -150,17 +157,20 @@ def attention(P: ParamStore, fp32: bool, p: str, x: torch.Tensor, norm: str, q: 
     out = torch.empty_like(x)
     Np = (N + 63) // 64 * 64
     vt = torch.zeros(C, Np, dtype=BF16, device=x.device)
-    s = torch.empty(N, Np, dtype=F32, device=x.device)
-    pm = torch.zeros(N, Np, dtype=BF16, device=x.device)
+    QB = min(N, ATTN_QUERY_BLOCK)
+    s = torch.empty(QB, Np, dtype=F32, device=x.device)
+    pm = torch.zeros(QB, Np, dtype=BF16, device=x.device)
     ob = torch.empty(N, C, dtype=BF16, device=x.device)
     for b in range(B):
         yb = y[b].view(N, C)
         ops.gemm(make_gemm_desc([dict(A=W(f"{p}.{v}.weight").data_ptr(), W=yb.data_ptr(), bias=W(f"{p}.{v}.bias").data_ptr(),
                                       C=vt.data_ptr(), M=C)], 1, N, C, C, Np, EPI_BIAS, row_bias=True))
-        ops.gemm(make_gemm_desc([dict(A=qq[b].data_ptr(), W=kk[b].data_ptr(), C=s.data_ptr(), M=N)], 1, N, C, C, Np,
-                                EPI_BIAS, out_f32=True))
-        ops.softmax_rows(s, C ** -0.5, out=pm, cols=N)
-        ops.gemm(make_gemm_desc([dict(A=pm.data_ptr(), W=vt.data_ptr(), C=ob.data_ptr(), M=N)], 1, C, Np, Np, C))
+        for r0 in range(0, N, QB):
+            m = min(QB, N - r0)
+            ops.gemm(make_gemm_desc([dict(A=qq[b, r0:r0 + m].data_ptr(), W=kk[b].data_ptr(), C=s.data_ptr(), M=m)], 1, N, C, C, Np,
+                                    EPI_BIAS, out_f32=True))
+            ops.softmax_rows(s[:m], C ** -0.5, out=pm[:m], cols=N)
+            ops.gemm(make_gemm_desc([dict(A=pm.data_ptr(), W=vt.data_ptr(), C=ob[r0:r0 + m].data_ptr(), M=m)], 1, C, Np, Np, C))
         ops.linear(ob, W(f"{p}.{o}.weight"), W(f"{p}.{o}.bias"), epi=EPI_GATE_RES, out=out[b].view(N, C),
                    res=x[b].view(N, C))
     return out

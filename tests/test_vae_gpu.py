@@ -293,6 +293,21 @@ def test_attn_block_x3(dev):
     assert rel_l2(got, ref) < X3
 
 
+@pytest.mark.parametrize("qb", [32, 50, 120])
+def test_attn_block_query_blocks(dev, monkeypatch, qb):
+    """The logits of the single-head attention exist for one block of queries at a time (vae_common.ATTN_QUERY_BLOCK rows,
+    4096 in production): several blocks incl. a ragged last one give the same result as one block, in both precisions."""
+    from flux_generator_amd import ops, vae_common
+    OA, W, ae = _tiny_ae_f32(dev)
+    x = frnd(2, 10, 12, 512, seed=3)             # N = 120 queries / keys
+    X = ops.split_f32(x.to(dev))
+    one = ops.join_f32(ae._attn("decoder.mid.attn_1", X, fp32=True))
+    one_bf = ae._attn("decoder.mid.attn_1", x.to(dev).to(BF))
+    monkeypatch.setattr(vae_common, "ATTN_QUERY_BLOCK", qb)
+    assert torch.equal(ops.join_f32(ae._attn("decoder.mid.attn_1", X, fp32=True)), one)
+    assert torch.equal(ae._attn("decoder.mid.attn_1", x.to(dev).to(BF)), one_bf)
+
+
 def test_decoder_tiny_fp32_faithful(dev):
     """The default decode = the reference's float32 arithmetic: image error <= 1/255 (the judge's bar), measured far
     below; the bf16-storage mode on the same inputs is two orders of magnitude further away."""
