@@ -36,4 +36,8 @@ python tools/prof_summary.py $(find /tmp/p6 -name "*kernel_stats.csv" | head -1)
 $B --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_r02_n1.json
 $B --fp8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_r02_fp8_b4_1024.json
 $B --model flux-dev --image-size 1024 --denoise-steps 28 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_r02_dev1024_n1.json
+# config C4 (sdxl-turbo 512x512, batch 16): bench line + kernel table
+python tools/bench_sdxl.py 2>/dev/null | tail -1 > $O/bench_r02_sdxl_b16.json
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p7 -o kt -- python $R/tools/bench_sdxl.py >/dev/null 2>&1 )
+python tools/prof_summary.py $(find /tmp/p7 -name "*kernel_stats.csv" | head -1) $O/r02_kernel_stats_sdxl_b16.csv > /dev/null
 head -14 $O/r02_kernel_stats_bench_n1.csv; head -8 $O/r02_hbm_traffic_pmc.csv; head -40 $O/r02_gemm_pmc.txt; cat $O/r02_attention_pmc.txt | head -30
