@@ -12,7 +12,6 @@ import warnings
 from dataclasses import dataclass
 from typing import Optional
 
-import torch
 
 from .autoencoder import AutoEncoder, AutoEncoderParams
 from .model import Flux, FluxParams

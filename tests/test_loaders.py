@@ -8,7 +8,6 @@ Reference: flux/model.py:85-97, flux/autoencoder.py:336-345, flux/utils.py:98-19
 flux/clip.py:96-125, stable_diffusion/stable_diffusion/model_io.py:49-164.
 """
 import json
-import os
 
 import pytest
 import torch

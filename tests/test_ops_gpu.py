@@ -5,7 +5,6 @@ Tolerances (floating point; the path computes in bf16 storage / fp32 accumulate)
     (bf16 output rounding alone is ~2e-3 rel-L2), exact for pure data movement;
   * index/permutation kernels (pack / unpack) are bit-exact.
 """
-import math
 
 import pytest
 import torch

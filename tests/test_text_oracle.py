@@ -2,13 +2,11 @@
 INDEPENDENT implementations in `transformers` (random tiny configs, weights copied through the
 reference's own sanitize key mapping), plus tokenizer behaviour on synthetic vocabularies."""
 import math
-import os
 
 import pytest
 import torch
 
 from conftest import rel_l2
-from oracle import flux_oracle as O
 from oracle import text_oracle as T
 
 
