@@ -109,8 +109,8 @@ const TileCfg kCfgs[] = {
     make_cfg_x3<128, 128, 2, 4, 3, 5>(),     // 47: cfg 40 "
     make_cfg<256, 256, 4, 2, 2, 5, 1>(),  // 48: cfg 43 with phase stamps (diagnostic: fluxhip_gemm_set_trace, tools/gemm_phase_trace.py)
     make_cfg_x3<256, 256, 4, 2, 2, 6>(),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
-    make_cfg<256, 224, 4, 2, 2, 6>(),     // 50: cfg 44 "
-    make_cfg<256, 192, 4, 2, 2, 6>(),     // 51: cfg 45 "
+    make_cfg_f8<256, 224, 4, 2, 2, 6>(),     // 50: cfg 44 "
+    make_cfg_f8<256, 192, 4, 2, 2, 6>(),     // 51: cfg 45 "
     make_cfg_f8<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
     make_cfg_f8<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
     make_cfg_f8<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
@@ -167,9 +167,12 @@ const Cand kX3ConvCands[] = {
 
 // fp8 kernels: the ping-pong tiles (time per K-step as measured for bf16: a K-step is the same 128 bytes per row) and
 // the simple-ring tiles for small shapes.
-// (the 256x256 / 256x224 / 256x192 ping-pong tiles do not fit 256 registers with 8-register fp8 operand tuples and
-//  spill: a spilled LDS-read destination is copied before the data lands, so they are not instantiated for fp8)
+// (the 256x256 ping-pong tile does not fit 256 registers with 8-register fp8 operand tuples and spills - a spilled
+//  LDS-read destination is copied before the data lands - so it is not instantiated for fp8; 256x224 / 256x192 fit since
+//  the fp8 loop reads and consumes a step's fragments inside one iteration, see the rotated group-0 loop in gemm_core.h)
 const Cand kF8Cands[] = {          // (t_step per 128-byte K-step, t_fixed) fitted to TUNE_FP8=1 tools/gemm_tune.py, M = 17408 / 1280
+    {50, 1, 1.460f, 13.2f},  // 256x224, ping-pong: 1.7-2.6 PFLOP/s, the fastest fp8 tile on every Flux shape at M >= 4352
+    {51, 1, 1.360f, 11.2f},  // 256x192, ping-pong (fit 1.30; nudged so that 256x224 keeps the shapes where both need the same rounds)
     {6, 1, 1.571f, 20.6f},   // 256x256, simple ring: 1.7-2.1 PFLOP/s on the large shapes
     {55, 1, 0.927f, 10.1f},  // 128x256, ping-pong
     {54, 1, 1.178f, 13.1f},  // 256x160  "

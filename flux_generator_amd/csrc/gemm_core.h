@@ -531,6 +531,48 @@ void gemm_nt_kernel(const GemmParams p) {
       const bool g0 = wave < LW;                                   // wave-uniform
       const int lw = g0 ? wave : wave - LW;
       bf16x8 a0[MI], w0[NJ], a1[MI], w1[NJ];
+      // FLAG_FP8: a fragment is born as the 8-register operand of the 16x16x128 MFMA (its two 16-byte halves are
+      // joined where they are read, while both are short-lived temporaries), not as two 4-register values joined at
+      // the MFMA: hipcc does not coalesce loop-carried 4-register values into a tuple and kept a second copy of every
+      // fragment (+80 VGPRs on the 256 x 192 tile: scratch, and a spilled ds_read destination is copied before its data lands).
+      typedef __attribute__((ext_vector_type(4))) int pp_i32x4;
+      typedef __attribute__((ext_vector_type(8))) int pp_i32x8;
+      pp_i32x8 A8[F8 ? MI : 1], W8[F8 ? NJ : 1];
+      auto read_both = [&](int slot_a, int slot_w) {
+        if constexpr (F8) {
+          const uint32_t aa0 = a_rd + slot_a * A_BYTES + foff[0], aa1 = a_rd + slot_a * A_BYTES + foff[1];
+          const uint32_t bb0 = b_rd + slot_w * B_BYTES + foff[0], bb1 = b_rd + slot_w * B_BYTES + foff[1];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            pp_i32x4 lo, hi;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lo) : "v"(aa0), "n"(i * 2048) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hi) : "v"(aa1), "n"(i * 2048) : "memory");
+            A8[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            pp_i32x4 lo, hi;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lo) : "v"(bb0), "n"(j * 2048) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hi) : "v"(bb1), "n"(j * 2048) : "memory");
+            W8[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        } else {
+          read_frags(a0, w0, slot_a, slot_w, 0);
+          read_frags(a1, w1, slot_a, slot_w, 1);
+        }
+      };
+      auto mma_both = [&]() {
+        if constexpr (F8) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(W8[j], A8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                           0x7f7f7f7f);
+        } else {
+          mma_step(a0, w0, a1, w1);
+        }
+      };
       // Two separate code paths, each with its own staging sources, prologue and loop (not one loop with a group
       // branch inside): every fragment and accumulator register is then written unconditionally in its loop -
       // which keeps hipcc from holding second copies of them - and a wave only carries the address registers
@@ -614,20 +656,44 @@ void gemm_nt_kernel(const GemmParams p) {
           wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
-        read_frags(a0, w0, 0, 0, 0);
-        read_frags(a1, w1, 0, 0, 1);
+        read_both(0, 0);
         int sa = 0, sw = 0;                        // ring slots of step kt
+        if constexpr (F8) {
+          // The same schedule with the loop rotated (first MFMA phase peeled): the fragments of step kt are read and
+          // consumed inside ONE iteration.  As loop-carried values (read at the bottom for the next trip) hipcc kept
+          // every 8-register operand twice - read into one set, v_mov'ed into another during the MFMA phase.
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          mma_both();
+          __builtin_amdgcn_sched_barrier(0);
+          wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();            // B1 of step 0
+          for (int kt = 1; kt < nkt; ++kt) {
+            const int sprev = sa;
+            sa ^= 1;
+            sw = sw == 2 ? 0 : sw + 1;
+            read_both(sa, sw);                     // memory phase of step kt - 1: fragments of step kt ...
+            if (kt + 1 < nkt) stage(kt + 1, sprev);   // ... and A(kt + 1) into the slot step kt - 1 has drained
+            __builtin_amdgcn_s_barrier();          // B2 of step kt - 1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma_both();
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt<0>();                       // my A(kt+1) pieces
+            __builtin_amdgcn_s_barrier();          // B1 of step kt
+          }
+          __builtin_amdgcn_s_barrier();            // B2 of the last step (group 1's MFMA phase)
+        } else
         for (int kt = 0; kt < nkt; ++kt) {
           const int sa1 = sa ^ 1, sw1 = sw == 2 ? 0 : sw + 1;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
-          mma_step(a0, w0, a1, w1);
+          mma_both();
           __builtin_amdgcn_sched_barrier(0);
           wait_vmcnt<0>();                         // my A(kt+1) pieces (issued one phase ago)
           __builtin_amdgcn_s_barrier();            // B1
           // (past the last step this re-reads a valid slot into registers nobody uses: keeps the body branch-free)
-          read_frags(a0, w0, sa1, sw1, 0);
-          read_frags(a1, w1, sa1, sw1, 1);
+          read_both(sa1, sw1);
           if (kt + 2 < nkt) stage(kt + 2, sa);
           __builtin_amdgcn_s_barrier();            // B2
           sa = sa1;
@@ -666,8 +732,7 @@ void gemm_nt_kernel(const GemmParams p) {
         int sa = 0, sw = 0;
         for (int kt = 0; kt < nkt; ++kt) {
           const int sw1 = sw == 2 ? 0 : sw + 1, sw2 = sw1 == 2 ? 0 : sw1 + 1;
-          read_frags(a0, w0, sa, sw, 0);
-          read_frags(a1, w1, sa, sw, 1);
+          read_both(sa, sw);
           if (kt + 2 < nkt) {
             stage(kt + 2, sw2);
             wait_vmcnt<PB>();                      // W(kt+1) landed; W(kt+2) may still fly
@@ -677,7 +742,7 @@ void gemm_nt_kernel(const GemmParams p) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slot kt are done before it is refilled
           __builtin_amdgcn_s_barrier();            // B1
           __builtin_amdgcn_sched_barrier(0);
-          mma_step(a0, w0, a1, w1);
+          mma_both();
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();            // B2
           sa ^= 1;

@@ -317,6 +317,8 @@ class Flux:
                 gs.append(g)
                 a_sc.append(ptr["asc"] + row0 * 4)
                 w_sc.append(wscale.data_ptr())
+            if (N, K) in forced:
+                kw["tile_cfg"] = forced[(N, K)]
             d = make_gemm_desc(gs, B, N, K, K, ldc, epi, **kw)
             sc = ops.make_fp8_scales(a_sc, w_sc, T)
             keep.extend([d, sc])

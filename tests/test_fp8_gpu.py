@@ -49,7 +49,8 @@ def test_quantize_rows_bit_exact(dev, rows, K, f32):
 @pytest.mark.parametrize("M,N,K,cfg", [(300, 512, 256, 0), (1280, 3072, 3072, 0), (1280, 9216, 3072, 0), (100, 64, 128, 0),
                                         (512, 768, 1280, 55), (512, 768, 1280, 53), (512, 768, 1280, 1), (512, 768, 1280, 2),
                                         (512, 768, 1280, 3), (512, 768, 1280, 4), (512, 640, 1280, 54), (512, 384, 1280, 52),
-                                        (4352, 3072, 15360, 0)])
+                                        (4352, 3072, 15360, 0), (512, 896, 1280, 50), (512, 768, 1280, 51), (1280, 9216, 3072, 51),
+                                        (700, 1000, 384, 50), (4352, 3072, 15360, 51), (256, 192, 128, 51)])
 def test_gemm_fp8(dev, M, N, K, cfg):
     from flux_generator_amd import ops
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
@@ -73,7 +74,7 @@ def test_gemm_fp8(dev, M, N, K, cfg):
 
 
 def test_gemm_fp8_rejects_uninstantiated_tiles(dev):
-    """Tiles without an fp8 kernel (the 256-wide ping-pong tiles that would spill) are refused, not run."""
+    """Tiles without an fp8 kernel (the 256 x 256 ping-pong tile, which would spill) are refused, not run."""
     from flux_generator_amd import ops
     x, w = rnd(256, 256, seed=1), rnd(256, 256, seed=2)
     xq, xs = ops.quantize_rows_fp8(x)
