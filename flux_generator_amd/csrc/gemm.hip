@@ -108,7 +108,7 @@ const TileCfg kCfgs[] = {
     make_cfg<256, 128, 4, 2, 3, 5>(),     // 46: cfg 41 "
     make_cfg_x3<128, 128, 2, 4, 3, 5>(),     // 47: cfg 40 "
     make_cfg<256, 256, 4, 2, 2, 5, 1>(),  // 48: cfg 43 with phase stamps (diagnostic: fluxhip_gemm_set_trace, tools/gemm_phase_trace.py)
-    make_cfg_x3<256, 256, 4, 2, 2, 6>(),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
+    make_cfg_x3_f8<256, 256, 4, 2, 2, 6>(),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
     make_cfg_f8<256, 224, 4, 2, 2, 6>(),     // 50: cfg 44 "
     make_cfg_f8<256, 192, 4, 2, 2, 6>(),     // 51: cfg 45 "
     make_cfg_f8<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
@@ -167,11 +167,12 @@ const Cand kX3ConvCands[] = {
 
 // fp8 kernels: the ping-pong tiles (time per K-step as measured for bf16: a K-step is the same 128 bytes per row) and
 // the simple-ring tiles for small shapes.
-// (the 256x256 ping-pong tile does not fit 256 registers with 8-register fp8 operand tuples and spills - a spilled
-//  LDS-read destination is copied before the data lands - so it is not instantiated for fp8; 256x224 / 256x192 fit since
-//  the fp8 loop reads and consumes a step's fragments inside one iteration, see the rotated group-0 loop in gemm_core.h)
+// (the 256-wide ping-pong tiles fit 256 registers since the fp8 loop reads and consumes a step's fragments inside one
+//  iteration - the rotated group-0 loop in gemm_core.h - and the staging sources are 32-bit offsets from a scalar base;
+//  the 256x256 one keeps 76 bytes of scratch in its epilogue only)
 const Cand kF8Cands[] = {          // (t_step per 128-byte K-step, t_fixed) fitted to TUNE_FP8=1 tools/gemm_tune.py, M = 17408 / 1280
-    {50, 1, 1.460f, 13.2f},  // 256x224, ping-pong: 1.7-2.6 PFLOP/s, the fastest fp8 tile on every Flux shape at M >= 4352
+    {49, 1, 1.398f, 22.8f},  // 256x256, ping-pong: 1.9-2.2 PFLOP/s on the N >= 9216 shapes at M = 17408
+    {50, 1, 1.460f, 13.2f},  // 256x224, ping-pong: 1.7-2.6 PFLOP/s
     {51, 1, 1.360f, 11.2f},  // 256x192, ping-pong (fit 1.30; nudged so that 256x224 keeps the shapes where both need the same rounds)
     {6, 1, 1.571f, 20.6f},   // 256x256, simple ring: 1.7-2.1 PFLOP/s on the large shapes
     {55, 1, 0.927f, 10.1f},  // 128x256, ping-pong
@@ -227,7 +228,17 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
 }
 
 int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false, bool f8 = false) {
-  const int cfg_idx = cfg_code & 0xff;
+  int cfg_idx = cfg_code & 0xff;
+  if (!conv && cfg_idx >= 49 && cfg_idx <= 55) {
+    // the ping-pong tiles address their dense operands as scalar base + 32-bit byte offset per (group, batch); an
+    // operand of 4 GiB or more (no product shape comes near: 65536 x 5120 bf16 is 0.67 GB) goes to the plain-ring
+    // tile of the same shape (fp8: the 256 x 256 simple ring)
+    const long long esz = f8 ? 1 : 2;
+    bool ok = (long long)p.N * p.K * esz < (1ll << 32);
+    for (int g = 0; g < p.ngroups; ++g) ok = ok && (long long)p.g[g].M * p.lda * esz < (1ll << 32);
+    static const int plain[7] = {15, 18, 19, 10, 7, 23, 14};   // 49..55 -> same tile shape, PIPE 1 (53: 128 x 128 is cfg 7)
+    if (!ok) cfg_idx = f8 ? 6 : (x3 && cfg_idx != 49 ? 15 : plain[cfg_idx - 49]);
+  }
   int splits = cfg_code >> 8;
   if (splits < 1) splits = 1;
   if (cfg_idx <= 0 || cfg_idx >= kNumCfgs || splits > 16) return FLUXHIP_EINVAL;
@@ -242,6 +253,7 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
   p.tiles_n = (p.N + c.bn - 1) / c.bn;
   auto fn = f8 ? c.dense_f8 : x3 ? (conv ? c.conv_x3 : c.dense_x3) : (conv ? c.conv : c.dense);
   if (!fn) return FLUXHIP_EINVAL;                   // this tile has no fp32-faithful / fp8 instantiation
+
   const int slot = f8 ? 4 : (int)conv + 2 * (int)x3;
   if (!g_attr_set[cfg_idx][slot]) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) !=

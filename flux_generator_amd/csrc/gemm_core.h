@@ -581,6 +581,8 @@ void gemm_nt_kernel(const GemmParams p) {
         // ---- group 0: stages the activation tile.  Dense rows as pointers; conv rows as the two packed
         //      geometry registers of the implicit-GEMM loader (same encoding as cyx / cimg above).
         const char* src[PA];
+        uint32_t soff[PA];                 // dense rows: byte offset from the (wave-uniform) base of this group / batch
+        const char* const abase = (const char*)gA + (long long)b * a_bs * ESZ;
         int gyx[PA];
         uint32_t gimg[PA];
 #pragma unroll
@@ -588,7 +590,8 @@ void gemm_nt_kernel(const GemmParams p) {
           const int row = (lw + i * LW) * 8 + lr;
           const int grow = min(m0 + row, Mg - 1);
           if (AMODE == 0) {
-            src[i] = (const char*)gA + ((long long)b * a_bs + (long long)grow * p.lda) * ESZ + lc * 16;
+            src[i] = nullptr;
+            soff[i] = (uint32_t)grow * (uint32_t)(p.lda * ESZ) + lc * 16;      // < 4 GiB per (group, batch): checked by the launcher
           } else {
             const int hw = p.cv.Ho * p.cv.Wo;
             const int bb = grow / hw, rem = grow - bb * hw;
@@ -626,7 +629,9 @@ void gemm_nt_kernel(const GemmParams p) {
           for (int i = 0; i < PA; ++i) {
             const char* s_ = nullptr;
             if (AMODE == 0) {
-              s_ = src[i] + (long long)ks * (BK * 2) + a_adj;
+              uint32_t so = soff[i];
+              asm volatile("" : "+v"(so));           // opaque: keeps the 64-bit sum out of loop-invariant hoisting
+              s_ = abase + ((long long)ks * (BK * 2) + a_adj) + (size_t)so;            // scalar base + 32-bit lane offset
             } else if (!p.cv.ups) {
               const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj;
               // opaque copy: otherwise hipcc hoists the loop-invariant 64-bit cX + img * 16 of every piece out of the
@@ -701,11 +706,12 @@ void gemm_nt_kernel(const GemmParams p) {
         }
       } else {
         // ---- group 1: stages the weight tile (conv: weight column = tap * Cin + channel chunk)
-        const char* src[PB];
+        uint32_t woff[PB];                 // byte offset of the piece's row from the weight base of this group / batch
+        const char* const wbase = (const char*)gW + (long long)b * w_bs * ESZ;
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
           const int row = min(lw + i * LW, BPIECES - 1) * 8 + lr;
-          src[i] = (const char*)gW + ((long long)b * w_bs + (long long)min(n0 + row, N - 1) * K) * ESZ + lc * 16;
+          woff[i] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)(K * ESZ) + lc * 16;
         }
         auto stage = [&](int kt, int slot) {       // W(kt) -> weight slot `slot`
           long long a_adj_unused, w_adj;
@@ -719,7 +725,11 @@ void gemm_nt_kernel(const GemmParams p) {
           koff += w_adj;
 #pragma unroll
           for (int i = 0; i < PB; ++i)
-            glds16(src[i] + koff, smem + W_BASE + slot * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
+          {
+            uint32_t wo = woff[i];
+            asm volatile("" : "+v"(wo));
+            glds16(wbase + koff + (size_t)wo, smem + W_BASE + slot * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
+          }
         };
         stage(0, 0);
         if (nkt > 1) {
