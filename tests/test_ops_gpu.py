@@ -329,3 +329,24 @@ def test_euler_and_pack(dev):
     assert torch.equal(ops.unpack_latents(packed, 12, 20).cpu(), z.cpu())
     aff = ops.unpack_latents(packed, 12, 20, 0.3611, 0.1159)
     assert rel_l2(aff, z.float().cpu() / 0.3611 + 0.1159) < TOL
+
+
+def test_gemm_pingpong_falls_back_for_4gib_operands(dev):
+    """The ping-pong tiles address dense operands as scalar base + 32-bit byte offset; an activation whose rows span
+    4 GiB or more (here 2112 rows spaced 2 MiB apart) is routed to the plain-ring tile of the same shape instead
+    (same result as the product path's own pick on a compact copy)."""
+    from flux_generator_amd import ops
+    from flux_generator_amd.ops import make_gemm_desc
+    M, N, K, lda = 2112, 384, 128, 1 << 20                       # M * lda * 2 bytes = 4.1 GiB
+    big = torch.empty(M * lda, dtype=BF, device=dev)
+    A = big.view(M, lda)[:, :K]
+    a = rnd(M, K, seed=1).to(dev)
+    A.copy_(a)
+    w, b = rnd(N, K, seed=2, scale=K ** -0.5).to(dev), rnd(N, seed=3).to(dev)
+    ref = ops.linear(a.contiguous(), w, b)
+    for cfg in (51, 49, 55):
+        out = torch.zeros(M, N, dtype=BF, device=dev)
+        ops.gemm(make_gemm_desc([dict(A=A.data_ptr(), W=w.data_ptr(), bias=b.data_ptr(), C=out.data_ptr(), M=M)], 1, N, K, lda, N,
+                                tile_cfg=cfg))
+        assert rel_l2(out, ref) < 2e-3, cfg
+    del big
