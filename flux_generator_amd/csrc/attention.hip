@@ -401,6 +401,7 @@ extern "C" int fluxhip_attention_d128_bf16(const void* Q, const void* K, const v
   // fewer workgroups than two per CU: split the KV tiles over a second wave set instead (see attn_kernel)
   static const int variant = [] { const char* e = getenv("FLUXHIP_ATTN"); return e ? atoi(e) : 0; }();   // tuning knob (tools/attn_bench.py)
   if (variant == 2) return launch_attn<128, 0, 1, 1>(p, B, (hipStream_t)stream);
+  if (variant == 3 && T > 2 * KV) return launch_attn<128, 0, 2, 1>(p, B, (hipStream_t)stream);   // two wave sets even on large grids
   if ((long long)B * H * p.nqb < 384 && T > 2 * KV) return launch_attn<128, 0, 2, 1>(p, B, (hipStream_t)stream);
   return launch_attn<128, 0, 1, 1>(p, B, (hipStream_t)stream);
 }

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Time the head_dim-128 attention entry point on the Flux shapes (GPU box).  FLUXHIP_ATTN selects the kernel variant
-(0 auto, 2 = single wave set even on small grids); it is read once per process, so this script re-executes itself."""
+(0 auto, 2 = single wave set even on small grids, 3 = two wave sets even on large grids); it is read once per process, so this script re-executes itself."""
 import os, sys, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHAPES = [(1, 24, 1280), (1, 24, 4352), (4, 24, 1280), (1, 24, 200)]
+SHAPES = [(1, 24, 1280), (1, 24, 4352), (1, 24, 4608), (4, 24, 1280), (4, 24, 4352), (1, 24, 200)]
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import torch
     from flux_generator_amd import ops
