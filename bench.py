@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec (+ denoise-step ms) for Flux-schnell 512x512 2-step on MI355X.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` — for N > 1 launched through
-torch.distributed.run, one rank per GPU.  A "step" is ONE pass of the hot path over one batch of
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.  For N > 1 the job is one rank per GPU over RCCL:
+either the caller launches it through ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (then
+WORLD_SIZE must equal N), or a plain ``python bench.py --gpus N`` re-executes itself under torch.distributed.run
+(127.0.0.1 rendezvous, a free port).  ``--dry-run`` runs the launch / sharding / collective skeleton on CPU (gloo, no
+kernels) so the N-rank path is testable without GPUs.  A "step" is ONE pass of the hot path over one batch of
 synthetic input on every rank: B images/GPU x (2 denoise steps [Flux forward + Euler] + VAE decode),
 inputs (x_T, txt, vec) already resident in HBM.  Weak scaling: every rank generates its own images,
 no data-path collective; the only collective is the timing barrier/max.
@@ -41,7 +44,7 @@ def flux_forward_flops(L: int, S: int, D: int = 3072, depth: int = 19, singles: 
     return f + 2 * (64 * L + 4096 * S) * D + 2 * 64 * L * D
 
 
-def cpu_baseline_sample(T: int, threads: int) -> dict:
+def cpu_baseline_sample(T: int, threads: int, S: int = 256) -> dict:
     """Oracle (port) on the host cores: 3 double + 8 single blocks (after a warm-up block) at full Flux width, T tokens,
     bf16-representable weights, fp32 math; extrapolated to 2 x (19 double + 38 single) per image."""
     from oracle import flux_oracle as O
@@ -50,7 +53,6 @@ def cpu_baseline_sample(T: int, threads: int) -> dict:
     shapes = {k: v for k, v in O.flux_weight_shapes(P).items() if k.startswith(("double_blocks.0", "single_blocks.0"))}
     W = O.init_weights(shapes, seed=0)
     g = torch.Generator().manual_seed(0)
-    S = 256
     img, txt = torch.randn(1, T - S, 3072, generator=g), torch.randn(1, S, 3072, generator=g)
     vec = torch.randn(1, 3072, generator=g)
     ids = torch.zeros(1, T, 3, dtype=torch.int32)
@@ -100,6 +102,66 @@ def pmc_traffic(label: str) -> dict:
             "traffic_source": f"profiles/r02_hbm_traffic_pmc.csv: {best['kernel']}"}
 
 
+def relaunch_under_torchrun(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` (one rank per GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args) -> None:
+    """The N-rank job's skeleton on CPU (gloo): process group, job seed + full-batch prior slice + rank-0 conditioning
+    broadcast (parallel.shard_generation_inputs), the timing barrier / max-reduce, the uint8 gather — everything but
+    the kernels.  Prints the JSON line with "dry_run": true; `value` is null."""
+    import torch.distributed as dist
+    from flux_generator_amd import parallel
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    B, lat = args.batch, 8
+    S = 512 if args.model == "flux-dev" else 256
+    calls = []
+
+    def cond():
+        calls.append(rank)
+        g = torch.Generator().manual_seed(1234)
+        return (torch.randn(1, S, 64, generator=g) * 0.1).to(torch.bfloat16), torch.randn(1, 32, generator=g).to(torch.bfloat16)
+
+    x_T, txt, vec, shard = parallel.shard_generation_inputs(B * world, (lat, lat, 16), 1234, dev, cond)
+    assert x_T.shape[0] == B and shard == (rank * B, rank * B + B) and (calls == [0] if rank == 0 else calls == [])
+    dist.barrier()
+    t0 = time.perf_counter()
+    img = (x_T.float().mean(dim=-1, keepdim=True).expand(-1, -1, -1, 3) * 0 + (rank + 1.5) / 255.0).contiguous()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    allel = [torch.zeros_like(el) for _ in range(world)]
+    dist.all_gather(allel, el)
+    gathered = parallel.gather_images(parallel.to_uint8(img).contiguous(), B * world)
+    if rank == 0:
+        assert gathered.shape == (B * world, lat, lat, 3)
+        assert [int(gathered[r * B, 0, 0, 0]) for r in range(world)] == list(range(1, world + 1))
+        print(json.dumps({"metric": "dry run (no kernels)", "value": None, "unit": "images/sec", "n_gpus": world, "dry_run": True,
+                          "steps": args.steps, "warmup": args.warmup, "scaling": "weak", "backend": "gloo",
+                          "ranks_joined": world, "conditioning_evaluated_on_ranks": [0],
+                          "per_rank_ms": [float(t.item()) * 1e3 for t in allel],
+                          "config": {"workload": "launch / sharding / collective skeleton", "global_batch": B * world}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,12 +176,25 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="run a few steps for rocprofv3, print nothing else")
+    ap.add_argument("--guidance", type=float, default=None, help="default 4.0 (7.0 for flux-dev, BASELINE.json configs[2])")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo skeleton of the N-rank job: launch, sharding, broadcast, "
+                    "barrier, max-reduce and gather, no kernels (tests/test_distributed_cpu.py)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus))
     args.batch = args.batch or (4 if args.fp8 else 1)
     args.image_size = args.image_size or (1024 if args.fp8 else 512)
     args.denoise_steps = args.denoise_steps or (4 if args.fp8 else 2)
+    args.guidance = args.guidance if args.guidance is not None else (7.0 if args.model == "flux-dev" else 4.0)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python bench.py --gpus N` or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    if args.dry_run:
+        return dry_run(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # BENCH_FORCE_DIST=1: create the RCCL process group even at world size 1, so a single-GPU box runs exactly the
@@ -148,7 +223,8 @@ def main() -> None:
 
     B = args.batch
     lat = args.image_size // 8
-    L, S = (lat // 2) ** 2, 256
+    # T5 sequence length: 256 for schnell, 512 for dev (flux/utils.py:210 of the reference; txt2image.py pads to it)
+    L, S = (lat // 2) ** 2, (512 if args.model == "flux-dev" else 256)
     # synthetic conditioning, resident in HBM before the timed region.  Multi-GPU: the job is ONE
     # batch of B x world images of one prompt, sharded by image exactly like FluxPipeline.generate_latents under
     # torchrun (flux_generator_amd/parallel.py): rank 0 holds the (synthetic) T5 / CLIP embeddings and broadcasts them
@@ -166,7 +242,7 @@ def main() -> None:
 
     def one_pass():
         x, x_ids = pipe._prepare_latent_images(x_T)
-        for x in pipe._denoising_loop(x, x_ids, txt, txt_ids, vec, num_steps=args.denoise_steps, guidance=4.0):
+        for x in pipe._denoising_loop(x, x_ids, txt, txt_ids, vec, num_steps=args.denoise_steps, guidance=args.guidance):
             pass
         return pipe.decode(x, (lat, lat))
 
@@ -189,9 +265,13 @@ def main() -> None:
         img = one_pass()
     sync_all()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert img.shape == (B, args.image_size, args.image_size, 3) and bool(torch.isfinite(img).all())
@@ -203,7 +283,7 @@ def main() -> None:
     # ---- denoise-step latency (one Flux forward + Euler) with HIP events on the launch stream
     x, x_ids = pipe._prepare_latent_images(x_T)
     tvec = torch.full((B,), 1.0, dtype=torch.bfloat16, device=dev)
-    gvec = torch.full((B,), 4.0, dtype=torch.bfloat16, device=dev)
+    gvec = torch.full((B,), args.guidance, dtype=torch.bfloat16, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 5
     pipe._flow_step(x, x_ids, txt, txt_ids, vec, tvec, gvec)      # capture outside the timed region (the image loop may use the other graph)
@@ -273,6 +353,8 @@ def main() -> None:
             "value": total_images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
+            "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms), "ranks": per_rank_ms},
+            "collectives": (f"RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())} (torch.distributed nccl backend)" if use_dist else None),
             "dtype": "fp8 e4m3 (block Linears: weights per-channel, activations per-token; residual stream / attention / VAE as in bf16 mode)" if args.fp8 else "bf16",
             "data": "synthetic",
             "config": {"workload": f"{args.model.replace('flux-', 'Flux-')} {args.image_size}x{args.image_size} {args.denoise_steps}-step, "
@@ -288,7 +370,7 @@ def main() -> None:
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_sample(L + S, torch.get_num_threads())
+            out["cpu_baseline"] = cpu_baseline_sample(L + S, torch.get_num_threads(), S)
     # RCCL prints its version banner through C stdio (flushed at exit when stdout is a pipe).  Every rank flushes it
     # now, then a barrier, then rank 0 prints: the JSON line is the LAST line of the job's output.
     def flush_c_stdio():

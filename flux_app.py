@@ -64,6 +64,8 @@ class FluxAPI:
             self.current_model = name
         return self.pipeline
 
+    DECODE_BATCH = 4
+
     def generate_images(self, prompt: str, model: str = "schnell", width: int = 512, height: int = 512,
                         steps: Optional[int] = None, guidance: float = 4.0, seed: Optional[int] = None,
                         batch_size: int = 1, n_iter: int = 1, return_pil: bool = False):
@@ -91,9 +93,14 @@ class FluxAPI:
         for x_t in latents:
             pass
         out = []
-        for i in range(n):
-            img = pipe.decode(x_t[i:i + 1]) if sd else pipe.decode(x_t[i:i + 1], latent_size)
-            arr = (img[0] * 255).to(torch.uint8).cpu().numpy()
+        # decode in batches (the reference decodes one image at a time, flux_app.py:186-192): up to DECODE_BATCH latents per
+        # VAE pass, one device->host copy per batch; float -> uint8 by truncation like the reference
+        arrs = []
+        for i in range(0, n, self.DECODE_BATCH):
+            chunk = x_t[i:i + self.DECODE_BATCH]
+            img = pipe.decode(chunk) if sd else pipe.decode(chunk, latent_size)
+            arrs.extend((img * 255).to(torch.uint8).cpu().numpy())
+        for arr in arrs:
             pil = Image.fromarray(np.asarray(arr))
             if return_pil:
                 out.append(pil)
@@ -121,7 +128,10 @@ class FluxAPI:
 
     def get_options(self):
         order = (0, 2, 1, 3)
+        # "sd_backend" is the reference's literal (Open-WebUI reads it); "sd_device" is an addition: this server process drives
+        # ONE GPU (libfluxhip binds one device per process); batches over several GPUs go through `torchrun txt2image.py`
         return {"sd_model_checkpoint": "stabilityai/stable-diffusion-2-1-base", "sd_backend": "Flux MLX",
+                "sd_device": "1 x MI355X per server process",
                 "sd_model_list": [dict(title=_MODELS[i][1], name=_MODELS[i][0], model_name=_MODELS[i][0]) for i in order]}
 
     def set_options(self, options: dict):

@@ -292,7 +292,9 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
 // the consumer computes the partials itself).
 int arm_gn_stats(GemmParams& p, int cfg_code, int B, int hw, int parities, void* gn_ws, int64_t gn_ws_bytes) {
   if (!gn_ws) return 0;
-  const TileCfg& c = kCfgs[cfg_code & 0xff];
+  const int idx = cfg_code & 0xff;      // e.g. a forced FLUXHIP_CONV_X3_CFG: launch() rejects it, do not index the table first
+  if (idx <= 0 || idx >= kNumCfgs || !kCfgs[idx].conv_x3) return 0;
+  const TileCfg& c = kCfgs[idx];
   const int wtm = c.bm / c.wm;
   if (hw % c.bm || p.N % 4) return 0;
   const int nchunks = parities * (hw / wtm);

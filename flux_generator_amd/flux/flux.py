@@ -14,6 +14,8 @@ synchronises when it reads (the analogue of the reference's ``mx.eval``).
 """
 from __future__ import annotations
 
+import os
+from collections import OrderedDict
 from typing import Optional, Tuple
 
 import torch
@@ -30,8 +32,10 @@ except Exception:  # pragma: no cover
 
 
 class FluxPipeline:
+    MAX_GRAPHS = 8      # captured hipGraphs kept per pipeline (LRU); each owns a private memory pool
+
     def __init__(self, name: Optional[str] = None, t5_padding: bool = True, model: Optional[str] = None,
-                 device: str = "cuda", use_graph: bool = True):
+                 device: str = "cuda", use_graph: bool = True, broadcast_weights: Optional[bool] = None):
         name = name if name is not None else model
         if name is None:
             raise ValueError("FluxPipeline needs a model name ('flux-schnell' or 'flux-dev')")
@@ -43,22 +47,71 @@ class FluxPipeline:
         self.device = _lib.bind_device(device)
         self.use_graph = use_graph
 
-        self.ae = load_ae(name, device=device)
-        self.flow = load_flow_model(name, device=device)
-        self.clip = load_clip(name, device=device)
+        # multi-GPU: broadcast_weights=True (or FLUX_BROADCAST_WEIGHTS=1) -> only rank 0 reads the checkpoints, the other
+        # ranks receive flow + AE weights over RCCL/xGMI; default: every rank reads its own copy
+        if broadcast_weights is None:
+            broadcast_weights = os.environ.get("FLUX_BROADCAST_WEIGHTS", "0") == "1"
+        self.ae = load_ae(name, device=device, from_rank0=broadcast_weights)
+        self.flow = load_flow_model(name, device=device, from_rank0=broadcast_weights)
+        # T5-XXL / CLIP (~10 GB) are built on first use: under torchrun only rank 0 ever evaluates them
+        # (parallel.shard_generation_inputs), so the other ranks never allocate or load them
+        self._t5 = self._clip = None
         self.clip_tokenizer = load_clip_tokenizer(name)
-        self.t5 = load_t5(name, device=device)
         self.t5_tokenizer = load_t5_tokenizer(name)
         self.sampler = FluxSampler(name)
-        self._graphs = {}
+        self._graphs = OrderedDict()
         self._graph_epoch = 0
 
+    # ------------------------------------------------------------------ text encoders (lazy; rank 0 only under torchrun)
+    @property
+    def t5(self):
+        if self._t5 is None:
+            self._t5 = load_t5(self.name, device=self.device)
+        return self._t5
+
+    @t5.setter
+    def t5(self, m):
+        self._t5 = m
+
+    @property
+    def clip(self):
+        if self._clip is None:
+            self._clip = load_clip(self.name, device=self.device)
+        return self._clip
+
+    @clip.setter
+    def clip(self, m):
+        self._clip = m
+
+    def _encodes_text(self) -> bool:
+        return not parallel.active() or parallel.world()[0] == 0
+
     def ensure_models_are_loaded(self):
+        if self._encodes_text():
+            self.t5, self.clip      # noqa: B018  (build them now)
         torch.cuda.synchronize(self.device)
 
     def reload_text_encoders(self):
-        self.t5 = load_t5(self.name, device=self.device)
-        self.clip = load_clip(self.name, device=self.device)
+        if self._encodes_text():
+            self._t5 = load_t5(self.name, device=self.device)
+            self._clip = load_clip(self.name, device=self.device)
+
+    # ------------------------------------------------------------------ captured graphs: bounded LRU
+    def _graph_get(self, key):
+        ent = self._graphs.get(key)
+        if ent is not None:
+            self._graphs.move_to_end(key)
+        return ent
+
+    def _graph_put(self, key, ent):
+        """Insert a captured graph; the least recently used ones beyond MAX_GRAPHS are dropped TOGETHER with the flow
+        model's workspace of their shape (a hipGraph pins its private pool and the launch plan's buffers: a long-lived
+        server that sees many image sizes must give both back)."""
+        self._graphs[key] = ent
+        while len(self._graphs) > self.MAX_GRAPHS:
+            old, _ = self._graphs.popitem(last=False)
+            if old[0] != "decode":
+                self.flow.release_workspace(*old[:3])
 
     def tokenize(self, text):
         t5_tokens = self.t5_tokenizer.encode(text, pad=self.t5_padding)
@@ -111,10 +164,10 @@ class FluxPipeline:
         if skip_mod:
             ws["mods"].copy_(mods)
         if self._graph_epoch != self.flow.plan_epoch:       # the flow model rebuilt its plans (enable_fp8): old graphs are stale
-            self._graphs = {k: v for k, v in self._graphs.items() if k[0] == "decode"}
-            self._graph_epoch = self.flow.plan_epoch
-        key = (B, S, L, "premod") if skip_mod else (B, S, L)
-        g = self._graphs.get(key)
+            self._graphs = OrderedDict((k, v) for k, v in self._graphs.items() if k[0] == "decode")
+            self._graph_epoch = self.flow.plan_epoch      # (enable_fp8 cleared the flow model's workspaces, pins included)
+        key = (B, S, L, "premod") if skip_mod else (B, S, L, "full")
+        g = self._graph_get(key)
         if g is None:
             # warm up once on a side stream (first-touch attribute calls), then capture
             side = torch.cuda.Stream(device=self.device)
@@ -125,7 +178,8 @@ class FluxPipeline:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.flow.run_plan(ws, skip_mod=skip_mod)
-            self._graphs[key] = g
+            self.flow.pin_workspace(B, S, L)
+            self._graph_put(key, g)
         g.replay()
         return ws["pred"]
 
@@ -202,8 +256,10 @@ class FluxPipeline:
         if not self.use_graph:
             return self.ae.decode_packed(x, latent_size, precision)
         key = ("decode", x.shape[0], tuple(latent_size), precision, self.ae._store.epoch)
-        ent = self._graphs.get(key)
+        ent = self._graph_get(key)
         if ent is None:
+            for k in [k for k in self._graphs if k[0] == "decode" and k[4] != key[4]]:
+                del self._graphs[k]           # decode graphs of an older parameter epoch can never be replayed again
             static_in = x.to(self.dtype).contiguous().clone()
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
@@ -214,7 +270,7 @@ class FluxPipeline:
             with torch.cuda.graph(g):
                 static_out = self.ae.decode_packed(static_in, latent_size, precision)
             ent = (g, static_in, static_out)
-            self._graphs[key] = ent
+            self._graph_put(key, ent)
         g, static_in, static_out = ent
         static_in.copy_(x)
         g.replay()

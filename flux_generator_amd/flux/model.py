@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes
 import os
 import math
+from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, Iterable, List, Optional, Tuple, Union
 
@@ -66,11 +67,11 @@ class Flux:
             raise FluxHipError("Flux needs a HIP device: there is no CPU fallback for the denoise path")
         self.device = _lib.bind_device(device)
         self._side = None            # side stream of the launch plan (modulation GEMV under the first blocks)
-        self._t_cache = {}           # modulation_tables: device copies of the timestep groups seen so far
+        self._t_cache = OrderedDict()   # modulation_tables: device copies of the timestep groups seen so far (LRU, 64)
         self.plan_epoch = 0          # bumped whenever the workspaces / launch plans are rebuilt (enable_fp8)
         _lib.load()
         self._alloc_parameters()
-        self._ws: Dict[Tuple[int, int, int], dict] = {}
+        self._ws: "OrderedDict[Tuple[int, int, int], dict]" = OrderedDict()   # per-(B, S, L) workspaces + launch plans, LRU
         self.fp8 = False             # enable_fp8(): e4m3 weights + per-token e4m3 activations on the fp8 matrix cores
         self._w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
 
@@ -193,6 +194,18 @@ class Flux:
                 raise ValueError(f"Missing parameters: {sorted(missing)[:5]} ...")
         return self
 
+    def broadcast_weights(self, src: int = 0) -> int:
+        """Multi-GPU start-up without N disk reads: rank `src` holds the loaded weights, every other
+        rank receives them over RCCL/xGMI (23.8 GB in ~0.2-0.4 s on the per-link-bound ring).  The modulation Linears
+        are views into one table, which is sent once.  fp8 copies are re-quantised locally (bit-identical)."""
+        from .. import parallel
+        views = {f"{k}.{leaf}" for k in self.mod_off for leaf in ("weight", "bias")}      # slices of mod_w / mod_b
+        tensors = [self.mod_w, self.mod_b] + [t for k, t in self._params.items() if k not in views]
+        n = parallel.broadcast_tensors(tensors, src)
+        for name, (q, sc) in self._w8.items():
+            ops.quantize_rows_fp8(self._params[f"{name}.weight"], out=q, scale=sc)
+        return n
+
     # ------------------------------------------------------------------ fp8 (BASELINE.json configs[4]; txt2image.py -q)
     _FP8_LAYERS = ("attn.qkv", "attn.proj", "mlp.layers.0", "mlp.layers.2", "linear1", "linear2")
 
@@ -246,10 +259,32 @@ class Flux:
         return len(names)
 
     # ------------------------------------------------------------------ workspace + launch plan
+    MAX_WORKSPACES = 8      # unpinned (B, S, L) workspaces kept (LRU); ~1 GB each at 1024 x 1024
+
+    def pin_workspace(self, B: int, S: int, L: int) -> None:
+        """A captured hipGraph holds the addresses of this shape's workspace: it must outlive the graph."""
+        ws = self._workspace(B, S, L)
+        ws["pins"] = ws.get("pins", 0) + 1
+
+    def release_workspace(self, B: int, S: int, L: int) -> None:
+        """Undo one pin_workspace; an unpinned workspace becomes evictable again (and is dropped right away when the
+        cache is over its bound)."""
+        ws = self._ws.get((B, S, L))
+        if ws is None:
+            return
+        ws["pins"] = max(0, ws.get("pins", 0) - 1)
+        self._evict_workspaces()
+
+    def _evict_workspaces(self) -> None:
+        free = [k for k, w in self._ws.items() if not w.get("pins", 0)]
+        for k in free[: max(0, len(free) - self.MAX_WORKSPACES)]:
+            del self._ws[k]
+
     def _workspace(self, B: int, S: int, L: int) -> dict:
         key = (B, S, L)
         ws = self._ws.get(key)
         if ws is not None:
+            self._ws.move_to_end(key)
             return ws
         P, D, dev = self.params, self.params.hidden_size, self.device
         mlp = int(D * P.mlp_ratio)
@@ -273,6 +308,7 @@ class Flux:
             ws["asc"] = buf(B * T, dtype=torch.float32)
         ws["plan"] = self._build_plan(ws)
         self._ws[key] = ws
+        self._evict_workspaces()
         return ws
 
     def _build_plan(self, ws: dict) -> list:
@@ -590,10 +626,12 @@ class Flux:
             tkey = (tuple(ts[k0:k0 + n]), B)
             t_all = self._t_cache.get(tkey)          # schedules repeat from image to image: no host->device copy then
             if t_all is None:
-                if len(self._t_cache) > 256:
-                    self._t_cache.clear()
                 t_all = torch.tensor(tkey[0], dtype=torch.float32, device=self.device).to(BF16).repeat_interleave(B).contiguous()
                 self._t_cache[tkey] = t_all
+                while len(self._t_cache) > 64:
+                    self._t_cache.popitem(last=False)
+            else:
+                self._t_cache.move_to_end(tkey)
             y_all = y.to(BF16).repeat(n, 1).contiguous()
             temb = torch.empty(R, 256, dtype=BF16, device=self.device)
             h1 = torch.empty(R, D, dtype=BF16, device=self.device)

@@ -59,29 +59,76 @@ def _load_safetensors(path: str):
     return load_file(path)
 
 
-def load_flow_model(name: str, hf_download: bool = True, device="cuda", seed: int = 0) -> Flux:
-    """flux/utils.py:98-121."""
+def _hub_file(repo_id: Optional[str], filename: Optional[str], hf_download: bool) -> Optional[str]:
+    """The reference falls back to hf_hub_download(repo_id, filename) when no path is configured (flux/utils.py:102-110,
+    128-136).  Here: a file already in the local Hugging Face cache is always used; a network download is attempted only
+    with FLUX_HUB_DOWNLOAD=1 (this build's environments have no egress, and a connection attempt per model load is not a
+    sensible default there).  None -> the caller random-initialises and says so."""
+    if not (hf_download and repo_id and filename):
+        return None
+    try:
+        from huggingface_hub import hf_hub_download, try_to_load_from_cache
+        hit = try_to_load_from_cache(repo_id, filename)
+        if isinstance(hit, str) and os.path.exists(hit):
+            return hit
+        if os.environ.get("FLUX_HUB_DOWNLOAD") == "1":
+            return hf_hub_download(repo_id, filename)
+    except Exception as e:      # no network, gated repo without a token, ...
+        warnings.warn(f"hub download of {repo_id}/{filename} failed: {type(e).__name__}: {e}")
+    return None
+
+
+def _receives_weights(from_rank0: bool) -> bool:
+    """True on the ranks that skip the disk read and take the weights from rank 0 over RCCL."""
+    from .. import parallel
+    return bool(from_rank0) and parallel.active() and parallel.world()[0] != 0
+
+
+def load_flow_model(name: str, hf_download: bool = True, device="cuda", seed: int = 0, from_rank0: bool = False) -> Flux:
+    """flux/utils.py:98-121.  from_rank0 (multi-GPU): only rank 0 reads the checkpoint (or draws the
+    random init); the other ranks allocate and receive the 23.8 GB over RCCL/xGMI (`Flux.broadcast_weights`)."""
     spec = configs[name]
     model = Flux(spec.params, device=device)
-    if spec.ckpt_path is not None:
-        model.load_weights(model.sanitize(_load_safetensors(spec.ckpt_path)))
+    if _receives_weights(from_rank0):
+        model.broadcast_weights(0)
+        return model
+    model = _load_flow_local(model, name, spec, seed, hf_download)
+    if from_rank0:
+        model.broadcast_weights(0)
+    return model
+
+
+def _load_flow_local(model: Flux, name: str, spec: ModelSpec, seed: int, hf_download: bool = True) -> Flux:
+    path = spec.ckpt_path or _hub_file(spec.repo_id, spec.repo_flow, hf_download)
+    if path is not None:
+        model.load_weights(model.sanitize(_load_safetensors(path)))
     else:
-        # the reference would hf_hub_download() here; this build has no hub access, so `hf_download` cannot be honoured
-        warnings.warn(f"{name}: no checkpoint configured (set FLUX_SCHNELL / FLUX_DEV; hub download is not available "
-                      "in this build); using random-init weights")
+        warnings.warn(f"{name}: no checkpoint configured (set FLUX_SCHNELL / FLUX_DEV, or FLUX_HUB_DOWNLOAD=1 with network "
+                      "access, or pre-populate the Hugging Face cache); using random-init weights")
         model.init_random(seed)
     return model
 
 
-def load_ae(name: str, hf_download: bool = True, device="cuda", seed: int = 1) -> AutoEncoder:
-    """flux/utils.py:124-147."""
+def load_ae(name: str, hf_download: bool = True, device="cuda", seed: int = 1, from_rank0: bool = False) -> AutoEncoder:
+    """flux/utils.py:124-147.  from_rank0: as for load_flow_model."""
     spec = configs[name]
     ae = AutoEncoder(spec.ae_params, device=device)
-    if spec.ae_path is not None:
-        ae.load_weights(ae.sanitize(_load_safetensors(spec.ae_path)))   # strict: encoder.* keys are skipped explicitly
+    if _receives_weights(from_rank0):
+        ae._store.broadcast(0)
+        return ae
+    ae = _load_ae_local(ae, name, spec, seed, hf_download)
+    if from_rank0:
+        ae._store.broadcast(0)
+    return ae
+
+
+def _load_ae_local(ae: AutoEncoder, name: str, spec: ModelSpec, seed: int, hf_download: bool = True) -> AutoEncoder:
+    path = spec.ae_path or _hub_file(spec.repo_id, spec.repo_ae, hf_download)
+    if path is not None:
+        ae.load_weights(ae.sanitize(_load_safetensors(path)))   # strict: encoder.* keys are skipped explicitly
     else:
-        warnings.warn(f"{name}: no AE checkpoint configured (set AE; hub download is not available in this build); "
-                      "using random-init weights")
+        warnings.warn(f"{name}: no AE checkpoint configured (set AE, or FLUX_HUB_DOWNLOAD=1 with network access, or "
+                      "pre-populate the Hugging Face cache); using random-init weights")
         ae.init_random(seed)
     return ae
 

@@ -230,6 +230,16 @@ _gn_ws = {}
 _gn_ws_retired = []
 
 
+def _grow_gn_ws(old: Optional[torch.Tensor], need_bytes: int, device) -> torch.Tensor:
+    """The GroupNorm scratch buffer grows GEOMETRICALLY (at least x2): a captured hipGraph may still launch kernels that
+    point at an outgrown buffer, so those are kept — at most log2(max need) of them, together smaller than the live one.
+    The total is therefore bounded by twice the largest request ever made, however many shapes a server sees."""
+    if old is not None:
+        _gn_ws_retired.append(old)
+    n = max(need_bytes // 4, 1 << 18, 2 * (old.numel() if old is not None else 0))
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
 def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6,
                    silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _bf16c(x, "x")
@@ -239,9 +249,7 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     ws = _gn_ws.get(x.device)
     need = (B * ((H * W_ + 31) // 32) * Cc + B * groups) * 2 * 4
     if ws is None or ws.numel() * 4 < need:
-        if ws is not None:
-            _gn_ws_retired.append(ws)      # a captured hipGraph may still launch kernels that point at it
-        ws = torch.empty(max(need // 4, 1 << 18), dtype=torch.float32, device=x.device)
+        ws = _grow_gn_ws(ws, need, x.device)
         _gn_ws[x.device] = ws
     _check(_lib.load().fluxhip_groupnorm_silu_bf16(_p(x), _p(gamma), _p(beta), _p(out), B, H * W_, Cc, groups, eps,
                                                     int(silu), _p(ws), ws.numel() * 4, _stream()),
@@ -411,7 +419,7 @@ def conv2d_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], strid
                                          ctypes.byref(nck) if gn_stats else None,
                                          _p(_zeros16(x.device)), _stream()), "fluxhip_conv2d_x3")
     if nck.value > 0:
-        out._gn = (gws, nck.value)
+        out._gn = (gws, nck.value, out._version)      # valid for exactly these contents of `out`
     return out
 
 
@@ -451,7 +459,7 @@ def conv_up2x_x3(x: torch.Tensor, w4: torch.Tensor, b: Optional[torch.Tensor], o
                                             ctypes.byref(nck) if gn_stats else None,
                                             _p(_zeros16(x.device)), _stream()), "fluxhip_conv_up2x_x3")
     if nck.value > 0:
-        out._gn = (gws, nck.value)
+        out._gn = (gws, nck.value, out._version)      # valid for exactly these contents of `out`
     return out
 
 
@@ -462,8 +470,10 @@ def groupnorm_silu_x3(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
     if out is None:
         out = torch.empty_like(x)
     st = getattr(x, "_gn", None)
+    if st is not None and st[2] != x._version:
+        st = None      # x was modified in place after the conv that produced it: its epilogue statistics are stale -> full pass
     if st is not None and (Cc // groups) % 4 == 0:     # partial sums (per channel quad) left by the epilogue of the conv that produced x: finalize + apply only
-        gws, nck = st
+        gws, nck, _ = st
         _check(_lib.load().fluxhip_groupnorm_apply_x3(_p(x[0]), x.stride(0), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")),
                                                       _p(out[0]), out.stride(0), B, H * W_, Cc, groups, eps, int(silu),
                                                       _p(gws), gws.numel() * 4, nck, _stream()), "fluxhip_groupnorm_apply_x3")
@@ -471,9 +481,7 @@ def groupnorm_silu_x3(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
     ws = _gn_ws.get(x.device)
     need = (B * ((H * W_ + 31) // 32) * Cc + B * groups) * 2 * 4
     if ws is None or ws.numel() * 4 < need:
-        if ws is not None:
-            _gn_ws_retired.append(ws)
-        ws = torch.empty(max(need // 4, 1 << 18), dtype=torch.float32, device=x.device)
+        ws = _grow_gn_ws(ws, need, x.device)
         _gn_ws[x.device] = ws
     _check(_lib.load().fluxhip_groupnorm_silu_x3(_p(x[0]), x.stride(0), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")),
                                                  _p(out[0]), out.stride(0), B, H * W_, Cc, groups, eps, int(silu), _p(ws),

@@ -126,6 +126,82 @@ def shard_generation_inputs(n_images: int, latent_shape, seed: Optional[int], de
     return x_T, txt, vec, (lo, hi)
 
 
+def broadcast_tensors(tensors, src: int = 0, bucket_bytes: int = 1 << 28) -> int:
+    """In-place broadcast of a list of (contiguous) parameter tensors from rank `src` — SURVEY.md §8(e).2: the optional
+    one-time weight broadcast when only rank `src` reads the checkpoint from disk.  xGMI rings are per-link bound
+    (~153 GB/s), so large tensors go as they are (one collective each, no staging copy) and the many small ones
+    (biases, norm scales) are coalesced into `bucket_bytes` staging buffers instead of one launch-bound collective each.
+    Returns the number of bytes broadcast.  No-op without a process group."""
+    if not active():
+        return 0
+    rank, _ = world()
+    total, small = 0, []
+
+    def flush():
+        if not small:
+            return
+        flat = torch.cat([t.reshape(-1).view(torch.uint8) for t in small])
+        dist.broadcast(flat, src=src)
+        if rank != src:
+            off = 0
+            for t in small:
+                n = t.numel() * t.element_size()
+                t.reshape(-1).view(torch.uint8).copy_(flat[off:off + n])
+                off += n
+        small.clear()
+
+    pending = 0
+    for t in tensors:
+        if not t.is_contiguous():
+            raise ValueError("broadcast_tensors needs contiguous tensors (views of one buffer: pass the buffer)")
+        n = t.numel() * t.element_size()
+        total += n
+        if n >= (1 << 22):
+            dist.broadcast(t.view(-1).view(torch.uint8), src=src)     # raw bytes: bf16 is not supported by every gloo build
+        else:
+            small.append(t)
+            pending += n
+            if pending >= bucket_bytes:
+                flush()
+                pending = 0
+    flush()
+    return total
+
+
+_DTYPES = [torch.bfloat16, torch.float32, torch.float16, torch.int32, torch.int64, torch.uint8]
+
+
+def broadcast_from(make, device, src: int = 0):
+    """`make()` -> list of tensors runs on rank `src` ONLY (text towers: the other ranks never build or evaluate them);
+    count / dtypes / shapes travel in one int64 header, then the raw bytes, over RCCL (gloo in the CPU tests).
+    Returns the list on every rank.  Without a process group it is just `make()`."""
+    rank, W = world()
+    if not active():
+        return [t.to(device) for t in make()]
+    MAXT, MAXD = 8, 6
+    hdr = torch.zeros(1 + MAXT * (2 + MAXD), dtype=torch.int64, device=device)
+    ts = None
+    if rank == src:
+        ts = [t.to(device).contiguous() for t in make()]
+        if len(ts) > MAXT or any(t.dim() > MAXD for t in ts):
+            raise ValueError("broadcast_from: at most 8 tensors of at most 6 dims")
+        h = [len(ts)]
+        for t in ts:
+            h += [_DTYPES.index(t.dtype), t.dim()] + list(t.shape) + [0] * (MAXD - t.dim())
+        hdr[: len(h)] = torch.tensor(h, dtype=torch.int64)
+    dist.broadcast(hdr, src=src)
+    h = [int(v) for v in hdr.tolist()]
+    if rank != src:
+        ts = []
+        for i in range(h[0]):
+            o = 1 + i * (2 + MAXD)
+            ts.append(torch.empty(h[o + 2: o + 2 + h[o + 1]], dtype=_DTYPES[h[o]], device=device))
+    for t in ts:
+        if t.numel():
+            dist.broadcast(t.view(-1).view(torch.uint8), src=src)
+    return ts
+
+
 def to_uint8(images: torch.Tensor) -> torch.Tensor:
     """(x*255).astype(uint8): float->uint8 TRUNCATION like the reference (txt2image.py:133,144)."""
     return (images * 255).to(torch.uint8)

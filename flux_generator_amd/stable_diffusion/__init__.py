@@ -1,36 +1,80 @@
 """StableDiffusion / StableDiffusionXL pipelines over the HIP hot path (mirror of the reference's
 stable_diffusion/stable_diffusion/__init__.py:19-306): same class names, constructor arguments and
 generator methods (``generate_latents`` yields x_t per step — no conditioning yield —, ``decode``).
-image2image / VAE encoder are out of the hot-path scope."""
+image2image / VAE encoder are out of the hot-path scope.
+
+Multi-GPU: under torch.distributed (one process per GPU) ``generate_latents`` shards the batch by image
+exactly like FluxPipeline — job seed from rank 0, text towers evaluated on rank 0 ONLY and their outputs broadcast over
+RCCL, the prior AND the ancestral sampler's per-step noise drawn for the full batch on every rank and sliced, yields are the
+LOCAL images (``self.shard``), ``gather_images`` collects uint8 images on rank 0.  No collective inside a step."""
 from __future__ import annotations
 
 import time
+from collections import OrderedDict
 from typing import Optional, Tuple
 
 import torch
 
-from .. import _lib, ops
+from .. import _lib, ops, parallel
 from .model_io import (_DEFAULT_MODEL, load_autoencoder, load_diffusion_config, load_text_encoder, load_tokenizer,
                        load_unet)
 from .sampler import SimpleEulerAncestralSampler, SimpleEulerSampler
 
 
+class _LazyTower:
+    """A text tower built on first use: under torchrun only rank 0 ever evaluates it, the other ranks never allocate it."""
+
+    def __init__(self, load):
+        self._load, self._m = load, None
+
+    def get(self):
+        if self._m is None:
+            self._m = self._load()
+        return self._m
+
+
 class StableDiffusion:
+    MAX_GRAPHS = 6      # captured hipGraphs kept (LRU): each owns a private pool of ~1-6 GB at batch 16
+
     def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True):
         # the HIP path computes in bf16 storage / fp32 accumulate whatever `float16` says
         self.dtype = torch.bfloat16
         self.device = _lib.bind_device(device)
         self.use_graph = use_graph
-        self._graphs = {}
+        self._graphs = OrderedDict()
+        self.shard = None
         self.diffusion_config = load_diffusion_config(model)
         self.unet = load_unet(model, float16, device=device)
-        self.text_encoder = load_text_encoder(model, float16, device=device)
+        self._towers = {"text_encoder": _LazyTower(lambda: load_text_encoder(model, float16, device=device))}
         self.autoencoder = load_autoencoder(model, False, device=device)
         self.sampler = SimpleEulerSampler(self.diffusion_config)
         self.tokenizer = load_tokenizer(model)
 
+    @property
+    def text_encoder(self):
+        if "text_encoder" not in self._towers:        # StableDiffusionXL renames it (reference: `del self.text_encoder`)
+            raise AttributeError("text_encoder")
+        return self._towers["text_encoder"].get()
+
+    def _encodes_text(self) -> bool:
+        return not parallel.active() or parallel.world()[0] == 0
+
     def ensure_models_are_loaded(self):
+        if self._encodes_text():
+            for t in self._towers.values():
+                t.get()
         torch.cuda.synchronize(self.device)
+
+    def _graph_get(self, key):
+        ent = self._graphs.get(key)
+        if ent is not None:
+            self._graphs.move_to_end(key)
+        return ent
+
+    def _graph_put(self, key, ent):
+        self._graphs[key] = ent
+        while len(self._graphs) > self.MAX_GRAPHS:
+            self._graphs.popitem(last=False)       # graph + its static buffers + its private pool go together
 
     def _tokenize(self, tokenizer, text: str, negative_text: Optional[str] = None):
         """__init__.py:34-46."""
@@ -49,19 +93,21 @@ class StableDiffusion:
         return conditioning
 
     def _denoising_step(self, x_t, t, t_prev, conditioning, cfg_weight: float = 7.5, text_time=None, noise=None,
-                        key: Optional[torch.Generator] = None):
+                        key: Optional[torch.Generator] = None, coef_dev: Optional[torch.Tensor] = None, shard=None):
         """__init__.py:67-82.  One UNet step is ~1700 kernel launches; with use_graph they are captured ONCE per
         (shape, cfg) into a hipGraph over static input buffers: the timestep is a device tensor and the sampler's
         (ca, cb, cc) live in a float32[3] device buffer (fluxhip_axpbypcz_dev_bf16), so every step of every run
         replays the same graph.  The ancestral sampler's per-step noise is drawn from the run's seeded generator
-        `key` outside the graph and copied into a static buffer."""
+        `key` outside the graph and copied into a static buffer.  coef_dev: this step's row of
+        `sampler.coeff_table` (device float32[3]; `_denoising_loop` uploads the whole table once per run) — without it the
+        coefficients are computed and uploaded here.  shard: (lo, hi, n_total) of a multi-GPU run (noise rows)."""
         if noise is None and self.sampler.needs_noise:
-            noise = self.sampler.draw_noise(x_t, key)
+            noise = self.sampler.draw_noise(x_t, key, shard)
         if not self.use_graph:
             return self._denoising_step_eager(x_t, t, t_prev, conditioning, cfg_weight, text_time, noise)
         key_ = ("step", tuple(x_t.shape), tuple(conditioning.shape), float(cfg_weight), text_time is not None,
                 noise is not None)
-        ent = self._graphs.get(key_)
+        ent = self._graph_get(key_)
         nb = len(x_t) * (2 if cfg_weight > 1 else 1)
         if ent is None:
             sx, sc = x_t.clone(), conditioning.clone()
@@ -78,7 +124,7 @@ class StableDiffusion:
             with torch.cuda.graph(g):
                 out = self._denoising_step_dev(sx, st, scoef, sc, cfg_weight, stt, sn)
             ent = (g, sx, sc, stt, sn, st, scoef, out)
-            self._graphs[key_] = ent
+            self._graph_put(key_, ent)
         g, sx, sc, stt, sn, st, scoef, out = ent
         sx.copy_(x_t)
         sc.copy_(conditioning)
@@ -88,7 +134,9 @@ class StableDiffusion:
         if sn is not None:
             sn.copy_(noise)
         st.fill_(float(t))
-        scoef.copy_(torch.tensor(self.sampler.coeffs(t, t_prev), dtype=torch.float32), non_blocking=False)
+        if coef_dev is None:
+            coef_dev = torch.tensor(self.sampler.coeffs(t, t_prev), dtype=torch.float32).to(self.device)
+        scoef.copy_(coef_dev)                  # device -> device: nothing host-side between two replays
         g.replay()
         return out.clone()
 
@@ -111,22 +159,57 @@ class StableDiffusion:
         return self.sampler.step(self._eps(x_t, t_unet, conditioning, cfg_weight, text_time), x_t, t, t_prev, noise)
 
     def _denoising_loop(self, x_T, T, conditioning, num_steps: int = 50, cfg_weight: float = 7.5, text_time=None,
-                        key: Optional[torch.Generator] = None):
+                        key: Optional[torch.Generator] = None, shard=None):
         """__init__.py:84-100."""
         x_t = x_T
-        for t, t_prev in self.sampler.timesteps(num_steps, start_time=T):
-            x_t = self._denoising_step(x_t, t, t_prev, conditioning, cfg_weight, text_time, key=key)
+        steps = self.sampler.timesteps(num_steps, start_time=T)
+        coefs = self.sampler.coeff_table(steps, self.device) if self.use_graph else None
+        for i, (t, t_prev) in enumerate(steps):
+            if len(x_t) == 0:          # more ranks than images: keep the job generator in step, nothing to compute
+                if self.sampler.needs_noise:
+                    self.sampler.draw_noise(x_t, key, shard)
+                yield x_t
+                continue
+            x_t = self._denoising_step(x_t, t, t_prev, conditioning, cfg_weight, text_time, key=key,
+                                       coef_dev=None if coefs is None else coefs[i], shard=shard)
             yield x_t
+
+    # ------------------------------------------------------------------ multi-GPU front half (SURVEY.md §8(e))
+    def _job_inputs(self, n_images: int, latent_size, seed, make_conditioning):
+        """seed, generator, the base conditioning tensors (as computed for ONE image, on rank 0 only, broadcast), the
+        local slice of the prior and `shard` = (lo, hi, n_total) — or shard None without a process group."""
+        ch = self.autoencoder.latent_channels
+        if not parallel.active():
+            seed = int(time.time()) if seed is None else seed
+            g = torch.Generator(device=self.device).manual_seed(seed)
+            self.shard = (0, n_images)
+            return g, make_conditioning(), None, None
+        seed = parallel.broadcast_seed(int(time.time()) if seed is None else seed, self.device)
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        cond = parallel.broadcast_from(make_conditioning, self.device)
+        rank, W = parallel.world()
+        lo, hi = parallel.shard_range(n_images, rank, W)
+        self.shard = (lo, hi)
+        x_T = self.sampler.sample_prior((n_images, *latent_size, ch), dtype=self.dtype, key=g, device=self.device,
+                                        rows=(lo, hi))
+        return g, cond, x_T, (lo, hi, n_images)
+
+    def gather_images(self, images: torch.Tensor, n_images: int):
+        """Decoded float images [n_local,H,W,3] of this rank -> uint8 (truncating, like the reference's CLI) -> gathered to
+        rank 0 in batch order over RCCL (None on the other ranks); with one process it is just the conversion."""
+        return parallel.gather_images(parallel.to_uint8(images).contiguous(), n_images)
 
     def generate_latents(self, text: str, n_images: int = 1, num_steps: int = 50, cfg_weight: float = 7.5,
                          negative_text: str = "", latent_size: Tuple[int, int] = (64, 64), seed=None):
         """__init__.py:102-129."""
-        seed = int(time.time()) if seed is None else seed
-        g = torch.Generator(device=self.device).manual_seed(seed)
-        conditioning = self._get_text_conditioning(text, n_images, cfg_weight, negative_text)
-        x_T = self.sampler.sample_prior((n_images, *latent_size, self.autoencoder.latent_channels), dtype=self.dtype,
-                                        key=g, device=self.device)
-        yield from self._denoising_loop(x_T, self.sampler.max_time, conditioning, num_steps, cfg_weight, key=g)
+        g, cond, x_T, shard = self._job_inputs(n_images, latent_size, seed,
+                                               lambda: [self._get_text_conditioning(text, 1, cfg_weight, negative_text)])
+        n_local = n_images if shard is None else shard[1] - shard[0]
+        conditioning = cond[0].repeat_interleave(n_local, dim=0) if n_local != 1 else cond[0]
+        if x_T is None:
+            x_T = self.sampler.sample_prior((n_images, *latent_size, self.autoencoder.latent_channels), dtype=self.dtype,
+                                            key=g, device=self.device)
+        yield from self._denoising_loop(x_T, self.sampler.max_time, conditioning, num_steps, cfg_weight, key=g, shard=shard)
 
     def decode(self, x_t, precision: Optional[str] = None):
         """__init__.py:166-169: clip(vae.decode(x_t) / 2 + 0.5, 0, 1), fused into the last conv.  float32 arithmetic
@@ -135,8 +218,10 @@ class StableDiffusion:
         if not self.use_graph:
             return self.autoencoder.decode_image(x_t, precision)
         key = ("decode", tuple(x_t.shape), precision, self.autoencoder._store.epoch)
-        ent = self._graphs.get(key)
+        ent = self._graph_get(key)
         if ent is None:
+            for k in [k for k in self._graphs if k[0] == "decode" and k[3] != key[3]]:
+                del self._graphs[k]           # decode graphs of an older parameter epoch can never be replayed again
             sx = x_t.to(self.dtype).contiguous().clone()
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
@@ -147,7 +232,7 @@ class StableDiffusion:
             with torch.cuda.graph(g):
                 out = self.autoencoder.decode_image(sx, precision)
             ent = (g, sx, out)
-            self._graphs[key] = ent
+            self._graph_put(key, ent)
         g, sx, out = ent
         sx.copy_(x_t)
         g.replay()
@@ -158,11 +243,20 @@ class StableDiffusionXL(StableDiffusion):
     def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True):
         super().__init__(model, float16, device, use_graph)
         self.sampler = SimpleEulerAncestralSampler(self.diffusion_config)
-        self.text_encoder_1 = self.text_encoder
+        self._towers = {"text_encoder_1": self._towers["text_encoder"],
+                        "text_encoder_2": _LazyTower(lambda: load_text_encoder(model, float16, model_key="text_encoder_2",
+                                                                               device=device))}
         self.tokenizer_1 = self.tokenizer
-        del self.tokenizer, self.text_encoder
-        self.text_encoder_2 = load_text_encoder(model, float16, model_key="text_encoder_2", device=device)
+        del self.tokenizer
         self.tokenizer_2 = load_tokenizer(model, merges_key="tokenizer_2_merges", vocab_key="tokenizer_2_vocab")
+
+    @property
+    def text_encoder_1(self):
+        return self._towers["text_encoder_1"].get()
+
+    @property
+    def text_encoder_2(self):
+        return self._towers["text_encoder_2"].get()
 
     def _get_text_conditioning(self, text: str, n_images: int = 1, cfg_weight: float = 7.5, negative_text: str = ""):
         """__init__.py:206-229."""
@@ -179,12 +273,17 @@ class StableDiffusionXL(StableDiffusion):
     def generate_latents(self, text: str, n_images: int = 1, num_steps: int = 2, cfg_weight: float = 0.0,
                          negative_text: str = "", latent_size: Tuple[int, int] = (64, 64), seed=None):
         """__init__.py:231-267."""
-        seed = int(time.time()) if seed is None else seed
-        g = torch.Generator(device=self.device).manual_seed(seed)
-        conditioning, pooled = self._get_text_conditioning(text, n_images, cfg_weight, negative_text)
+        g, cond, x_T, shard = self._job_inputs(n_images, latent_size, seed,
+                                               lambda: list(self._get_text_conditioning(text, 1, cfg_weight, negative_text)))
+        n_local = n_images if shard is None else shard[1] - shard[0]
+        conditioning, pooled = cond
+        if n_local != 1:
+            conditioning = conditioning.repeat_interleave(n_local, dim=0)
+            pooled = pooled.repeat_interleave(n_local, dim=0)
         time_ids = torch.tensor([[512, 512, 0, 0, 512, 512.0]] * len(pooled), device=self.device)
         text_time = (pooled, time_ids)
-        x_T = self.sampler.sample_prior((n_images, *latent_size, self.autoencoder.latent_channels), dtype=self.dtype,
-                                        key=g, device=self.device)
+        if x_T is None:
+            x_T = self.sampler.sample_prior((n_images, *latent_size, self.autoencoder.latent_channels), dtype=self.dtype,
+                                            key=g, device=self.device)
         yield from self._denoising_loop(x_T, self.sampler.max_time, conditioning, num_steps, cfg_weight,
-                                        text_time=text_time, key=g)
+                                        text_time=text_time, key=g, shard=shard)

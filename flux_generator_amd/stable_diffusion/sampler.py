@@ -40,11 +40,14 @@ class SimpleEulerSampler:
     def max_time(self):
         return len(self._sigmas) - 1
 
-    def sample_prior(self, shape, dtype=torch.bfloat16, key: Optional[torch.Generator] = None, device="cuda"):
-        """sampler.py:56-60: N(0,1) * sigma_max / sqrt(sigma_max^2 + 1)."""
+    def sample_prior(self, shape, dtype=torch.bfloat16, key: Optional[torch.Generator] = None, device="cuda", rows=None):
+        """sampler.py:56-60: N(0,1) * sigma_max / sqrt(sigma_max^2 + 1).  rows=(lo, hi): multi-GPU — the FULL batch is
+        drawn (every rank, same seed: "one seed -> one batch" for any world size) and rows [lo, hi) are kept."""
         noise = torch.randn(shape, generator=key, device=device, dtype=torch.float32)
+        if rows is not None:
+            noise = noise[rows[0]:rows[1]]
         s = self._sigmas[-1]
-        return (noise * float(s * torch.rsqrt(s.square() + 1))).to(dtype)
+        return (noise * float(s * torch.rsqrt(s.square() + 1))).to(dtype).contiguous()
 
     def sigmas(self, t) -> torch.Tensor:
         return _interp(self._sigmas, torch.as_tensor(t, dtype=torch.float32))
@@ -66,6 +69,12 @@ class SimpleEulerSampler:
     def coeffs(self, t, t_prev):
         """(ca, cb, cc) of x' = ca x + cb eps + cc noise for the step t -> t_prev (host floats)."""
         return self._coeffs(t, t_prev)
+
+    def coeff_table(self, steps, device) -> torch.Tensor:
+        """float32 [len(steps), 3] on `device`: the (ca, cb, cc) of every (t, t_prev) of a run, uploaded ONCE — the
+        captured step graph reads its coefficients from a device buffer that is refreshed by a device-side copy of one
+        row, so no per-step host->device transfer sits between graph replays."""
+        return torch.tensor([self._coeffs(t, tp) for t, tp in steps], dtype=torch.float32).to(device)
 
     def step(self, eps_pred: torch.Tensor, x_t: torch.Tensor, t, t_prev, noise: Optional[torch.Tensor] = None):
         """sampler.py:76-85: ((sigma^2+1)^.5 x + eps (sigma_prev - sigma)) (sigma_prev^2+1)^-.5"""
@@ -89,9 +98,14 @@ class SimpleEulerAncestralSampler(SimpleEulerSampler):
         inv = torch.rsqrt(sigma_prev2 + 1)
         return float((sigma2 + 1).sqrt() * inv), float((sigma_down - sigma) * inv), float(sigma_up * inv)
 
-    def draw_noise(self, x_t: torch.Tensor, key: Optional[torch.Generator] = None) -> torch.Tensor:
+    def draw_noise(self, x_t: torch.Tensor, key: Optional[torch.Generator] = None, shard=None) -> torch.Tensor:
         """The fresh N(0,1) of sampler.py:100, drawn from the run's seeded generator (the reference's
-        mx.random.seed(seed) fixes this noise too, __init__.py:242-243)."""
+        mx.random.seed(seed) fixes this noise too, __init__.py:242-243).  shard=(lo, hi, n_total): multi-GPU — every
+        rank draws the step's FULL-batch noise from the job's generator and keeps its rows."""
+        if shard is not None:
+            lo, hi, n = shard
+            full = torch.randn((n, *x_t.shape[1:]), generator=key, device=x_t.device, dtype=torch.float32)
+            return full[lo:hi].to(x_t.dtype).contiguous()
         return torch.randn(x_t.shape, generator=key, device=x_t.device, dtype=torch.float32).to(x_t.dtype)
 
     def step(self, eps_pred, x_t, t, t_prev, noise: Optional[torch.Tensor] = None,

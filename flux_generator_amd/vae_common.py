@@ -35,7 +35,7 @@ class ParamStore:
         self.master = {k: torch.empty(*shp, dtype=F32, device=device) for k, shp in shapes.items()}
         self._pad64 = set(pad64)         # weights whose last (input-channel) dim is zero-padded to a multiple of 64
         self._derived: Dict[Tuple[str, str], Tuple[int, torch.Tensor]] = {}
-        self.epoch = 0                   # bumped by load(): part of the pipelines' decode-graph keys
+        self.epoch = 0                   # bumped by load() / init_random() / broadcast(): part of the pipelines' decode-graph keys
 
     def __contains__(self, name: str) -> bool:
         return name in self.master
@@ -43,6 +43,7 @@ class ParamStore:
     def init_random(self, seed: int) -> None:
         """MLX defaults: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for conv / linear weight and bias, (1, 0) for norms."""
         g = torch.Generator(device=self.device).manual_seed(seed)
+        self.epoch += 1
         for name, t in self.master.items():
             wt = self.master[f"{name.rsplit('.', 1)[0]}.weight"]
             if wt.dim() == 1:
@@ -84,8 +85,21 @@ class ParamStore:
         if kind == "x3up":
             src = ops.subpixel_weights(src)
         d = src.to(BF16) if kind == "bf16" else ops.split_f32(src)
+        if ent is not None and ent[1].shape == d.shape:
+            # the master changed (in-place edit, load, init_random): rebuild INTO the existing operand tensor — captured
+            # hipGraphs (and the launch plans of the callers) hold its address, so it is never freed or replaced
+            ent[1].copy_(d)
+            d = ent[1]
         self._derived[(name, kind)] = (t._version, d)
         return d
+
+    def broadcast(self, src: int = 0) -> None:
+        """Every master parameter from rank `src` over RCCL (multi-GPU: only rank `src` read the checkpoint), derived
+        operand layouts marked stale (rebuilt in place on next use)."""
+        from . import parallel
+        parallel.broadcast_tensors(list(self.master.values()), src)
+        self.epoch += 1
+        self._derived = {k: (-1, d) for k, (_, d) in self._derived.items()}
 
 
 # Queries per block of the single-head VAE attention: the float32 logits buffer is ATTN_QUERY_BLOCK x N (64 MiB at

@@ -464,3 +464,93 @@ def test_fp8_toggle_and_lora_after_first_generation(dev, monkeypatch):
     c.flow.enable_fp8()
     x_a, x_c = run(a), run(c)
     assert torch.equal(x_a, x_c) and not torch.equal(x_a, x_late)
+
+
+# ------------------------------------------------------------------------------------------ long-lived server hygiene
+def test_pipeline_caches_are_bounded(dev, monkeypatch):
+    """A server that sees many image sizes: captured hipGraphs (FluxPipeline._graphs), the flow model's per-shape workspaces
+    (Flux._ws) and the timestep cache are LRU-bounded and a graph is dropped together with its workspace.  20 shapes are
+    cycled twice: the second cycle must not grow HBM use over the first (steady state), the caches stay within their
+    bounds, and the results of a re-captured shape equal its first results bit for bit."""
+    import warnings
+    from flux_generator_amd.flux.flux import FluxPipeline
+    _tiny_flux_zoo(monkeypatch)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe = FluxPipeline("flux-schnell", device=str(dev))
+    sizes = [(16 + 2 * i, 16) for i in range(20)]
+
+    def run(size):
+        x = pipe.generate_images("a cat", n_images=1, num_steps=2, latent_size=size, seed=3, progress=False,
+                                 reload_text_encoders=False)
+        torch.cuda.synchronize()
+        return x
+
+    first = run(sizes[0]).clone()
+    mem = []
+    for cycle in range(2):
+        for s in sizes:
+            run(s)
+        torch.cuda.synchronize()
+        mem.append(torch.cuda.memory_allocated(dev))
+        assert len(pipe._graphs) <= pipe.MAX_GRAPHS
+        pinned = [k for k, w in pipe.flow._ws.items() if w.get("pins", 0)]
+        assert len(pipe.flow._ws) - len(pinned) <= pipe.flow.MAX_WORKSPACES and len(pinned) <= pipe.MAX_GRAPHS
+        assert len(pipe.flow._t_cache) <= 64
+    assert mem[1] <= mem[0] + (1 << 20), f"HBM use grows from cycle to cycle: {mem}"
+    assert (16, 16) not in [k[2] for k in pipe._graphs if k[0] == "decode"]        # the first shape's graphs were evicted ...
+    assert torch.equal(run(sizes[0]), first)                                       # ... and re-capturing reproduces it
+
+
+def test_text_towers_are_built_on_rank0_only(dev, monkeypatch):
+    """Under torchrun only rank 0 evaluates T5-XXL / CLIP (parallel.shard_generation_inputs), so the other ranks must not
+    even construct them (~10 GB of HBM and the load time): the towers are lazy and `ensure_models_are_loaded` /
+    `reload_text_encoders` respect the rank."""
+    import warnings
+    from flux_generator_amd import parallel
+    from flux_generator_amd.flux.flux import FluxPipeline
+    _tiny_flux_zoo(monkeypatch)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe = FluxPipeline("flux-schnell", device=str(dev))
+        assert pipe._t5 is None and pipe._clip is None
+        monkeypatch.setattr(parallel, "active", lambda: True)
+        monkeypatch.setattr(parallel, "world", lambda: (1, 2))
+        pipe.ensure_models_are_loaded()
+        pipe.reload_text_encoders()
+        assert pipe._t5 is None and pipe._clip is None
+        monkeypatch.setattr(parallel, "world", lambda: (0, 2))
+        pipe.ensure_models_are_loaded()
+        assert pipe._t5 is not None and pipe._clip is not None
+
+
+def test_weight_broadcast_nccl_world1(dev, monkeypatch):
+    """FluxPipeline(broadcast_weights=True) under a real RCCL group (world 1): rank 0 loads / initialises, the
+    broadcast runs through RCCL (flow: modulation table + every Linear once; AE: float32 masters), images unchanged."""
+    import socket
+    import warnings
+    import torch.distributed as dist
+    from flux_generator_amd.flux.flux import FluxPipeline
+    _tiny_flux_zoo(monkeypatch)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = FluxPipeline("flux-schnell", device=str(dev))
+    want = plain.generate_images("a cat", n_images=1, num_steps=2, latent_size=(16, 16), seed=2, progress=False)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(dev))
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            pipe = FluxPipeline("flux-schnell", device=str(dev), broadcast_weights=True)
+        nbytes = pipe.flow.broadcast_weights(0)
+        assert nbytes == sum(t.numel() * 2 for t in [pipe.flow.mod_w, pipe.flow.mod_b]) + sum(
+            t.numel() * 2 for k, t in pipe.flow.parameters().items()
+            if not any(k.startswith(m + ".") for m in pipe.flow.mod_off))
+        got = pipe.generate_images("a cat", n_images=1, num_steps=2, latent_size=(16, 16), seed=2, progress=False)
+        assert torch.equal(got, want)
+    finally:
+        dist.destroy_process_group()

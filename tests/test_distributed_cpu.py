@@ -115,3 +115,114 @@ def test_two_rank_generation_inputs(n, per_image):
 def test_uint8_truncates_like_reference():
     from flux_generator_amd.parallel import to_uint8
     assert to_uint8(torch.tensor([0.0, 0.999, 1.0, 0.5])).tolist() == [0, 254, 255, 127]
+
+
+def _run_bench(*argv, env=None):
+    import json
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=300, env=e)
+    last = [l for l in r.stdout.splitlines() if l.strip()]
+    return r, (json.loads(last[-1]) if last and last[-1].startswith("{") else None)
+
+
+def test_bench_gpus2_launches_two_ranks():
+    """A plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) re-executes itself under torch.distributed.run and
+    two ranks join (--dry-run: gloo, no kernels); the JSON line is the last line of stdout and reports n_gpus = 2."""
+    r, out = _run_bench("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out is not None and out["n_gpus"] == 2 and out["ranks_joined"] == 2 and out["dry_run"] is True
+    assert out["conditioning_evaluated_on_ranks"] == [0] and len(out["per_rank_ms"]) == 2
+    assert out["config"]["global_batch"] == 2 and out["scaling"] == "weak"
+
+
+def test_bench_refuses_world_size_mismatch():
+    """--gpus must agree with the launcher's WORLD_SIZE: a mismatch is an error, not a silent 1-rank run."""
+    r, out = _run_bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and out is None and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def _worker_sd(rank, world, port, q):
+    """The stable_diffusion/ pipelines' sharding pieces (flux_generator_amd/stable_diffusion/__init__.py `_job_inputs`,
+    sampler rows / shard arguments) on CPU: broadcast_from evaluates the text-tower stand-in on rank 0 only; the prior and
+    the ancestral sampler's per-step noise are full-batch draws from the job seed, sliced."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from flux_generator_amd import parallel as P
+    from flux_generator_amd.stable_diffusion.config import DiffusionConfig
+    from flux_generator_amd.stable_diffusion.sampler import SimpleEulerAncestralSampler
+    calls = []
+
+    def towers():
+        calls.append(rank)
+        g = torch.Generator().manual_seed(5)
+        return [torch.randn(2, 7, 16, generator=g).bfloat16(), torch.randn(2, 12, generator=g), torch.arange(6, dtype=torch.int32)]
+
+    seed = P.broadcast_seed(41 if rank == 0 else 999, "cpu")
+    cond = P.broadcast_from(towers, "cpu")
+    g5 = torch.Generator().manual_seed(5)
+    ok = calls == ([0] if rank == 0 else []) and seed == 41
+    ok = ok and torch.equal(cond[0], torch.randn(2, 7, 16, generator=g5).bfloat16()) and cond[0].dtype == torch.bfloat16
+    ok = ok and torch.equal(cond[1], torch.randn(2, 12, generator=g5)) and torch.equal(cond[2], torch.arange(6, dtype=torch.int32))
+    n = 5
+    lo, hi = P.shard_range(n, rank, world)
+    sam = SimpleEulerAncestralSampler(DiffusionConfig())
+    g = torch.Generator().manual_seed(seed)
+    x = sam.sample_prior((n, 4, 4, 4), dtype=torch.float32, key=g, device="cpu", rows=(lo, hi))
+    n1 = sam.draw_noise(x, g, (lo, hi, n))
+    n2 = sam.draw_noise(x, g, (lo, hi, n))
+    gf = torch.Generator().manual_seed(seed)                     # what ONE process draws for the whole batch
+    fx = sam.sample_prior((n, 4, 4, 4), dtype=torch.float32, key=gf, device="cpu")
+    f1 = sam.draw_noise(fx, gf)
+    f2 = sam.draw_noise(fx, gf)
+    ok = ok and torch.equal(x, fx[lo:hi]) and torch.equal(n1, f1[lo:hi]) and torch.equal(n2, f2[lo:hi])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sd_sharding_pieces():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_sd, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
+def _worker_bcast_params(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from flux_generator_amd import parallel as P
+    g = torch.Generator().manual_seed(9)
+    shapes = [(3000, 1024), (7,), (33, 5), (1 << 21,), (2, 2)]       # one tensor above the 4 MiB direct-send threshold
+    want = [torch.randn(*s, generator=g).bfloat16() for s in shapes]
+    have = [w.clone() if rank == 0 else torch.zeros_like(w) for w in want]
+    nbytes = P.broadcast_tensors(have, 0, bucket_bytes=64)         # tiny bucket: several flushes
+    ok = nbytes == sum(w.numel() * 2 for w in want) and all(torch.equal(a, b) for a, b in zip(have, want))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_weight_broadcast():
+    """parallel.broadcast_tensors (the optional one-time weight broadcast when only rank 0 reads the checkpoint)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_bcast_params, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res

@@ -187,6 +187,67 @@ def test_full_size_fp8_properties(dev):
     assert torch.equal(ws["pred"], a)
 
 
+def test_c5_full_size_fp8_forward_b4(dev):
+    """BASELINE.json configs[4] at its per-GPU size — Flux-schnell, 1024 x 1024 (L = 4096), S = 256, batch 4: the fp8 launch
+    plan with its 17 408-row e4m3 / scale scratch (flux/model.py `a8` / `asc`), under test rather than only under bench.py.
+      1. the forward is repeatable bit for bit and hipGraph replay == eager;
+      2. image 0 of the batch == the batch-1 forward of the same latents to the e4m3 budget (tile picks / split-K change
+         with M, so not bit-equal): rel-L2 <= 2e-2; images with identical inputs inside one batch are bit-equal;
+      3. rel-L2 vs the bf16 forward of the SAME random-init model <= 5e-2 (3-bit mantissas on both GEMM operands);
+      4. zero-gate identity vs the oracle at full size: with every block's modulation zeroed the blocks are the identity,
+         so pred == final_layer(img_in(img)) computed by the fp32 oracle (<= 1e-2: those two Linears stay bf16)."""
+    from flux_generator_amd.flux.model import Flux
+    from flux_generator_amd.flux.utils import configs
+    P = configs["flux-schnell"].params
+    model = Flux(P, device=dev).init_random(3)
+    B, S, h, w = 4, 256, 128, 128
+    L = (h // 2) * (w // 2)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(B, h, w, 16, generator=g).to(BF)
+    z[3] = z[1]                                                  # two identical images in the batch
+    img, ids = O.prepare_latent_images(z)
+    txt = (torch.randn(1, S, P.context_in_dim, generator=g) * 0.5).to(BF).expand(B, -1, -1).contiguous()
+    tids = torch.zeros(B, S, 3, dtype=torch.int32)
+    vec = torch.randn(1, P.vec_in_dim, generator=g).to(BF).expand(B, -1).contiguous()
+    t = torch.full((B,), 0.75, dtype=BF)
+    args = [a.to(dev) for a in (img, ids, txt, tids, t, vec)]
+    ref16 = model(*args).float().cpu()
+    model.enable_fp8()
+    a = model(*args)
+    b = model(*args)
+    assert a.shape == (B, L, 64) and bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    ws = model._workspace(B, S, L)
+    assert ws["a8"].shape == (B * (S + L), 5 * P.hidden_size) and ws["asc"].shape == (B * (S + L),)
+    assert torch.equal(a[1], a[3]) and not torch.equal(a[0], a[1])
+    e16 = rel_l2(a, ref16)
+    one = model(*[x[:1].contiguous() for x in args])
+    e1 = rel_l2(a[:1], one.float().cpu())
+    print(f"C5 fp8 forward (B=4, T=4352): vs bf16 forward rel-L2 {e16:.2e}; image 0 vs its batch-1 forward {e1:.2e}")
+    assert e16 < 5e-2 and e1 < 2e-2
+    gr = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model.run_plan(ws)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(gr):
+        model.run_plan(ws)
+    ws["pred"].zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ws["pred"], a), "hipGraph replay differs from the eager fp8 plan"
+
+    keep = model.mod_off["final_layer.adaLN_modulation.layers.1"]
+    model.mod_w[:keep].zero_()
+    model.mod_b[:keep].zero_()
+    got = model(*args)
+    Wc = {k: v.float().cpu() for k, v in model.parameters().items()
+          if k.startswith(("img_in.", "time_in.", "vector_in.", "final_layer."))}
+    x = O.linear(img.float(), Wc["img_in.weight"], Wc["img_in.bias"])
+    v = O.mlp_embedder(Wc, "time_in", O.timestep_embedding(t, 256).float()) + O.mlp_embedder(Wc, "vector_in", vec.float())
+    assert rel_l2(got, O.last_layer(Wc, x, v)) < 1e-2
+
+
 def test_ln_modulate_fp8_fused_is_bit_identical(dev):
     """fluxhip_ln_modulate_fp8 (quantisation fused into the producer) == fluxhip_ln_modulate_bf16 followed by
     fluxhip_quantize_rows_fp8, byte for byte and scale for scale."""

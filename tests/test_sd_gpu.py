@@ -172,6 +172,51 @@ def test_sd_vae_decode_tiny(dev):
     assert rel_l2(ae.decode(z.to(dev), precision="bf16"), S.vae_decode(ocfg, W, z.float())) < 2e-2
 
 
+def test_sd_vae_decode_c4_size(dev):
+    """The SD / SDXL VAE decoder at BASELINE.json configs[3]'s size — the real AutoencoderConfig ((128, 256, 512, 512), 2 layers
+    per block, SDXL scaling 0.13025), batch 16 of 64 x 64 x 4 latents -> 16 x 512 x 512 x 3:
+      1. (batch 16, both precisions) repeatable bit for bit, range [0, 1], finite, identical latents in the batch give
+         bit-identical images, hipGraph replay == eager;
+      2. (batch 1, fp32-faithful default) image parity vs the float32 oracle S.sd_decode (vae.py:209-223,256-258 +
+         __init__.py:166-169): max-abs <= 1/255; the batch-16 image of the same latent equals the batch-1 image to 1e-4
+         rel-L2 (tile picks change with the batch);
+      3. (batch 1, bf16-storage opt-in) max-abs <= 0.03 like the tiny test."""
+    from flux_generator_amd.stable_diffusion.config import AutoencoderConfig
+    from flux_generator_amd.stable_diffusion.vae import Autoencoder
+    kw = dict(scaling_factor=0.13025)
+    ocfg = S.AutoencoderConfig(**kw)
+    W = O.init_weights(S.vae_decoder_weight_shapes(ocfg), seed=9, norm_jitter=0.2)
+    ae = Autoencoder(AutoencoderConfig(**kw), device=dev).load_weights(W)
+    z = torch.randn(16, 64, 64, 4, generator=torch.Generator().manual_seed(3)).to(BF)
+    z[5] = z[2]
+    zd = z.to(dev)
+    ref = S.sd_decode(ocfg, W, z[:1].float())
+    for prec in ("fp32", "bf16"):
+        a = ae.decode_image(zd, precision=prec)
+        b = ae.decode_image(zd, precision=prec)
+        assert a.shape == (16, 512, 512, 3) and a.dtype == torch.float32 and bool(torch.isfinite(a).all())
+        assert torch.equal(a, b) and torch.equal(a[5], a[2]) and not torch.equal(a[0], a[1])
+        assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 and float(a.std()) > 1e-3
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ae.decode_image(zd, precision=prec)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = ae.decode_image(zd, precision=prec)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, a)
+        one = ae.decode_image(zd[:1], precision=prec)
+        d = float((one.cpu() - ref).abs().max())
+        e = rel_l2(a[:1], one.cpu())
+        print(f"sd vae 512x512 ({prec}): batch-1 max-abs vs fp32 oracle {d:.2e}; batch-16 image 0 vs batch-1 rel-L2 {e:.2e}")
+        assert d <= (1.0 / 255 if prec == "fp32" else 0.03)
+        assert e < (1e-4 if prec == "fp32" else 1e-2)
+        del a, b, out, graph
+
+
 def test_sdxl_pipeline_surface(dev, monkeypatch):
     """StableDiffusionXL.generate_latents / decode drive end to end on a (patched-in) tiny model."""
     import warnings
@@ -216,6 +261,28 @@ def test_sdxl_pipeline_surface(dev, monkeypatch):
         e = list(pipe.generate_latents("a photo of a cat", seed=11, **kw))
         pipe.use_graph = True
         assert all(torch.equal(x, y) for x, y in zip(a, e)), "graph replay differs from the eager steps"
+        # the torchrun code path with a REAL RCCL process group of world_size 1: job seed broadcast,
+        # text towers -> broadcast_from, full-batch prior AND per-step ancestral noise drawn and sliced, uint8 gather —
+        # bit-identical to the plain single-process path on every step
+        import socket
+        import torch.distributed as dist
+        from flux_generator_amd import parallel
+        want = pipe.gather_images(pipe.decode(a[-1]), 2)
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device(dev))
+        try:
+            assert parallel.active()
+            d = list(pipe.generate_latents("a photo of a cat", seed=11, **kw))
+            assert pipe.shard == (0, 2) and all(torch.equal(x, y) for x, y in zip(a, d))
+            got = pipe.gather_images(pipe.decode(d[-1]), 2)
+            assert got.dtype == torch.uint8 and got.shape == (2, 32, 32, 3) and torch.equal(got, want)
+        finally:
+            dist.destroy_process_group()
         with pytest.raises(ValueError):
             model_io.load_unet("no/such-model")
     finally:

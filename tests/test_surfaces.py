@@ -82,13 +82,13 @@ def test_sd_routing_uses_sd_signature():
     import flux_app
     pipe = MagicMock()
     pipe.generate_latents.return_value = iter([torch.zeros(2, 8, 8, 4)])
-    pipe.decode.return_value = torch.zeros(1, 64, 64, 3)
+    pipe.decode.side_effect = lambda x, *a: torch.zeros(len(x), 64, 64, 3)     # latents are decoded in batches
     a = flux_app.FluxAPI()
     with patch.object(flux_app.FluxAPI, "init_pipeline", return_value=pipe):
         out = a.generate_images("p", model="stabilityai/sdxl-turbo", batch_size=2, guidance=0.0, return_pil=True)
     kw = pipe.generate_latents.call_args.kwargs
     assert kw["num_steps"] == 2 and kw["n_images"] == 2 and "latent_size" not in kw     # SD ignores width/height (:149-155)
-    assert len(out) == 2 and out[0].size == (64, 64)
+    assert len(out) == 2 and out[0].size == (64, 64) and pipe.decode.call_count == 1
 
 
 def test_port_helpers():
