@@ -115,6 +115,7 @@ const TileCfg kCfgs[] = {
     make_cfg_f8<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
     make_cfg_f8<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
     make_cfg_x3_f8<128, 256, 2, 4, 2, 6>(),     // 55: 128x256, ping-pong
+    make_cfg<256, 192, 4, 2, 2, 6, 1>(),        // 56: cfg 51 with stamps around the main loop, the split-K reduce-scatter segments and the epilogue (diagnostic)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -184,15 +185,37 @@ const Cand kF8Cands[] = {          // (t_step per 128-byte K-step, t_fixed) fitt
     {2, 2, 1.70f, 0.30f},  {3, 2, 1.35f, 2.90f},  {4, 2, 0.97f, 1.15f},
 };
 
-// Split-K workspace (fluxhip_set_workspace): [kSkMaxTiles] int32 hand-off counters, then fp32 partial tiles.
+// Split-K workspace (fluxhip_set_workspace): [kSkMaxTiles] int32 hand-off counters (reduce-scatter mode: arrival counters
+// in the first half, departure counters in the second), then fp32 partial tiles.
 constexpr int kSkMaxTiles = 16384;
 constexpr long long kSkFlagBytes = (long long)kSkMaxTiles * 4;
 char* g_ws = nullptr;
 long long g_ws_bytes = 0;
 constexpr float kHopUs = 20.0f, kHopNextUs = 8.0f;   // measured cost of the first / each further hand-off of a chain
+constexpr float kRsHopUs = 9.0f, kRsHopNextUs = 1.0f; // reduce-scatter hand-off (all S exchanges concurrent)
+int g_num_cus = 0;                                    // CUs of the bound device (reduce-scatter needs the whole grid resident)
+// FLUXHIP_SPLITK=chain (or fluxhip_gemm_set_splitk_mode(1)) keeps every split-K launch on the chain (A/B runs, diagnostics)
+bool g_rs_enabled = [] { const char* e = getenv("FLUXHIP_SPLITK"); return !(e && e[0] == 'c'); }();
+long long g_rs_launches = 0;
+
+// Can a split-K launch of `cfg` with S splits over `tiles` output tiles use the reduce-scatter hand-off?
+bool rs_ok(int cfg, int S, long long tiles, bool conv, bool x3, bool f8) {
+  if (!g_rs_enabled || conv || x3 || f8 || cfg < 49 || cfg > 56 || S < 2) return false;
+  const TileCfg& t = kCfgs[cfg];
+  const int mi = t.bm / t.wm / 16, nj = t.bn / (t.threads / 64 / t.wm) / 16;
+  if (mi % S && nj % S) return false;
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
+    g_num_cus = pr.multiProcessorCount;
+  }
+  if (tiles * S > g_num_cus || tiles > kSkMaxTiles / 2) return false;
+  return kSkFlagBytes + tiles * S * t.bm * t.bn * 4LL <= g_ws_bytes;
+}
 
 // returns cfg | (splits << 8)
-template <int NC>
+template <int NC, bool RS = false>
 int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbatch, int N, int K) {
   float best = 3.4e38f;
   int best_cfg = 4;
@@ -209,7 +232,9 @@ int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbat
         if (kSkFlagBytes + tiles * t.bm * t.bn * 4LL > g_ws_bytes) break;
       }
       const long long rounds = (tiles * S + slots - 1) / slots;
-      const float hop = S > 1 ? kHopUs + (float)(S - 2) * kHopNextUs : 0.f;
+      const float hop = S == 1 ? 0.f
+                        : (RS && rs_ok(c.cfg, S, tiles, false, false, false)) ? kRsHopUs + (float)(S - 2) * kRsHopNextUs
+                                                                             : kHopUs + (float)(S - 2) * kHopNextUs;
       const float cost = (float)rounds * ((float)((nkt + S - 1) / S) * c.t_step_us + c.t_fixed_us) + hop;
       if (cost < best) { best = cost; best_cfg = c.cfg | (S << 8); }
     }
@@ -224,19 +249,19 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
     return conv ? pick_from(kX3ConvCands, group_m, ngroups, nbatch, N, 3 * K)
                 : pick_from(kX3Cands, group_m, ngroups, nbatch, N, 3 * K);
   return conv ? pick_from(kConvCands, group_m, ngroups, nbatch, N, K)
-              : pick_from(kCands, group_m, ngroups, nbatch, N, K);
+              : pick_from<sizeof(kCands) / sizeof(kCands[0]), true>(kCands, group_m, ngroups, nbatch, N, K);
 }
 
 int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false, bool f8 = false) {
   int cfg_idx = cfg_code & 0xff;
-  if (!conv && cfg_idx >= 49 && cfg_idx <= 55) {
+  if (!conv && cfg_idx >= 49 && cfg_idx <= 56) {
     // the ping-pong tiles address their dense operands as scalar base + 32-bit byte offset per (group, batch); an
     // operand of 4 GiB or more (no product shape comes near: 65536 x 5120 bf16 is 0.67 GB) goes to the plain-ring
     // tile of the same shape (fp8: the 256 x 256 simple ring)
     const long long esz = f8 ? 1 : 2;
     bool ok = (long long)p.N * p.K * esz < (1ll << 32);
     for (int g = 0; g < p.ngroups; ++g) ok = ok && (long long)p.g[g].M * p.lda * esz < (1ll << 32);
-    static const int plain[7] = {15, 18, 19, 10, 7, 23, 14};   // 49..55 -> same tile shape, PIPE 1 (53: 128 x 128 is cfg 7)
+    static const int plain[8] = {15, 18, 19, 10, 7, 23, 14, 19};   // 49..56 -> same tile shape, PIPE 1 (53: 128 x 128 is cfg 7)
     if (!ok) cfg_idx = f8 ? 6 : (x3 && cfg_idx != 49 ? 15 : plain[cfg_idx - 49]);
   }
   int splits = cfg_code >> 8;
@@ -280,6 +305,9 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
       return FLUXHIP_EINVAL;                        // no (or too small a) split-K workspace
     p.sk_flag = (int*)g_ws;
     p.sk_part = (float*)(g_ws + kSkFlagBytes);
+    p.sk_mode = (!p.addvec && rs_ok(cfg_idx, splits, tiles, conv, x3, f8)) ? 1 : 0;
+    p.sk_depart = p.sk_flag + kSkMaxTiles / 2;
+    g_rs_launches += p.sk_mode != 0;
   }
   dim3 grid(tm_total * p.tiles_n * splits), block(c.threads);
   hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);
@@ -429,6 +457,14 @@ extern "C" int fluxhip_set_workspace(void* ws, int64_t bytes) {
   g_ws_bytes = ws ? bytes : 0;
   return FLUXHIP_OK;
 }
+
+extern "C" int fluxhip_gemm_set_splitk_mode(int mode) {
+  if (mode != 0 && mode != 1) return FLUXHIP_EINVAL;
+  g_rs_enabled = mode == 0;
+  return FLUXHIP_OK;
+}
+
+extern "C" int64_t fluxhip_gemm_rs_launches(void) { return g_rs_launches; }
 
 extern "C" int fluxhip_gemm_set_trace(void* buf) {
   g_trace = (unsigned long long*)buf;

@@ -93,6 +93,9 @@ struct GemmParams {
   int splits;            // split-K factor S (1 = off): S blocks share one output tile, see the split-K note below
   float* sk_part;        // [tiles][BM*BN] fp32 partial tiles (caller-provided workspace)
   int* sk_flag;          // [tiles] hand-off counters, zero between launches
+  int sk_mode;           // 0: chain (block s adds the partial of block s-1);  1: reduce-scatter (ping-pong tiles only, every
+                         //    split block resident at once: grid <= CUs) — see the split-K note at the hand-off
+  int* sk_depart;        // sk_mode 1: [tiles] departure counters (zero between launches; the last block to leave resets both)
   int wide_epi;          // outputs / residual / gate are 16-byte addressable: LDS-transposed epilogue
   unsigned long long* trace;  // FLAG_TIMED kernels only: [nblk][nwaves][8] summed segment cycles
   // FLAG_SPLIT kernels only ("bf16x3": fp32-faithful products on the bf16 matrix cores).  Every operand is a pair
@@ -181,6 +184,24 @@ void gemm_nt_kernel(const GemmParams p) {
   // dispatcher has already started, so the chain cannot deadlock even when the grid exceeds the chip.
   const int S = p.splits;
   int nblk = gridDim.x, bid = blockIdx.x, sidx = 0;
+  // Reduce-scatter split-K (sk_mode 1, see the hand-off after the main loop) exchanges its partials through memory, so the
+  // S blocks of a tile need not share an XCD — and should not: with K = 12288 / 15360 the main loop of the N = 3072
+  // projections is FABRIC-bound (phase trace: 1.0 us per K-step against 0.8 us of MFMA issue), because under the tile-major
+  // map below every XCD walks all M-tiles over all K, i.e. the 39 MB activation panel crosses the fabric 8 times (~410 MB per
+  // launch for 134 MB of operands).  Here the (split, tile) space is cut into one contiguous brick per XCD in
+  // (split-major, N-tile, M-tile) order — 240 blocks: every XCD owns ONE K range, 6 N-tiles and all 5 M-tiles — so an XCD
+  // reads a third of the activation panel (once per brick row) and its own weight panels: ~215 MB per launch.
+  bool rs_map = false;
+  if constexpr (PIPE == 6 && (FLAGS & (FLAG_SPLIT | FLAG_FP8)) == 0 && AMODE == 0) rs_map = S > 1 && p.sk_mode != 0;
+  int swz;
+  if (rs_map) {
+    const int T = nblk / S;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // position in XCD-brick order
+    sidx = lin / T;
+    bid = lin - sidx * T;          // tile id (flags, slab)
+    swz = bid;
+  } else {
   if (S > 1) {
     const int T = nblk / S, full = T >> 3, grp = 8 * S;
     if (bid < full * grp) {
@@ -195,7 +216,8 @@ void gemm_nt_kernel(const GemmParams p) {
     nblk = T;
   }
   const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  }
   const int TM = p.tiles_m_total;
   int tm = swz % TM;
   const int tn = swz / TM;
@@ -913,17 +935,99 @@ void gemm_nt_kernel(const GemmParams p) {
       asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_loop1)::"memory");
       if (p.trace && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p.trace[((long long)bid * NWAVES + wave) * 16 + i] = tsum[i];
+        for (int i = 0; i < 8; ++i) p.trace[((long long)blockIdx.x * NWAVES + wave) * 16 + i] = tsum[i];
       }
     }
 #undef GEMM_STAMP
   }
 
   // ---- split-K hand-off (see the block map above) ---------------------------------------------
-  // Release / acquire at agent scope, executed by ONE lane per block: the release (buffer_wbl2) walks the
+  // Owned fragment range of this block: everything unless the reduce-scatter hand-off below narrows it.
+  int oi_lo = 0, oi_hi = MI, oj_lo = 0, oj_hi = NJ;
+  // Mode 1, REDUCE-SCATTER (ping-pong bf16 tiles; every split block of the grid resident at once).  The chain below costs
+  // ~20 us for its first hop and ~8 us for each further one: S - 1 serial {store the whole fp32 tile, release fence =
+  // buffer_wbl2 walking an L2 that 30 other blocks are dirtying, flag, acquire, load the whole tile}.  Here the S blocks of
+  // a tile finish their K ranges together and EACH ends up owning 1/S of the tile (fragment rows if MI % S == 0, else
+  // fragment columns): a block stores the (S-1)/S it does not own WRITE-THROUGH (sc1: the bytes leave this XCD's L2 as they
+  // are written, so no release fence and no L2 walk), every storing wave drains vmcnt, the block arrives on the tile's
+  // counter, one lane polls it (relaxed) until all S have arrived, ONE agent acquire drops this CU's stale L1 lines, and the
+  // block adds its peers' partials of the fragments it owns (fixed peer order: deterministic) and runs the epilogue on
+  // them only.  All S hand-offs are concurrent; bytes per block: (S-1)/S of a tile out, the same in.  Placement
+  // independent (cdna guide, Guideline 16 R1); the blocks wait for EACH OTHER, so the launcher only selects this mode when
+  // the whole grid is resident (one block per CU, grid <= CUs).  The last block to leave a tile zeroes both counters.
+  constexpr bool RS_CAPABLE = PP && !X3 && !F8 && AMODE == 0;
+  bool rs = false;
+  if constexpr (RS_CAPABLE) {
+    if (S > 1 && p.sk_mode != 0) {
+      rs = true;
+      const bool by_rows = (MI % S) == 0;             // the launcher guarantees MI % S == 0 or NJ % S == 0
+      if (by_rows) { oi_lo = sidx * (MI / S); oi_hi = oi_lo + MI / S; }
+      else { oj_lo = sidx * (NJ / S); oj_hi = oj_lo + NJ / S; }
+      constexpr int F = MI * NJ;                        // fragments (1 KiB of fp32 each) per wave
+      // slab of this tile: [S sources][NWAVES][F][64 lanes] f32x4 (a source never writes the fragments it owns)
+      float* slab = p.sk_part + (size_t)bid * ((size_t)S * BM * BN);
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, S * BM * BN * 4, 0x00020000);
+      const int my_off = ((sidx * NWAVES + wave) * F) * 1024 + lane * 16;
+      // (Measured and dropped: when all S blocks verifiably share one XCD — they do under the observed dispatch order —
+      //  plain stores would keep the exchange inside that XCD's L2.  It is SLOWER in situ, 6.32 vs 6.12 ms for the 57 split
+      //  launches of a forward: 30 blocks x 131 KB of dirty partials per XCD evict the operand panels from the 4 MB L2 and
+      //  still have to be written back at the end of the kernel.  Write-through keeps the L2 clean and needs no placement.)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (i >= oi_lo && i < oi_hi && j >= oj_lo && j < oj_hi) continue;      // wave-uniform
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrc, my_off + (i * NJ + j) * 1024, 0,
+                                                 /*sc1: write-through*/ 16);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its write-through stores
+      unsigned long long t_rs1 = 0, t_rs2 = 0, t_rs3 = 0;
+      if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_rs1)::"memory");
+      __syncthreads();
+      int* arrive = p.sk_flag + bid;
+      if (tid == 0) {
+        __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv: this CU's L1 may hold last launch's slab lines
+      }
+      __syncthreads();
+      if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_rs2)::"memory");
+      const f32x4* rd = (const f32x4*)slab + (size_t)wave * F * 64 + lane;
+      for (int s2 = 0; s2 < S; ++s2) {                       // peers in index order (skipping myself): fixed summation order
+        if (s2 == sidx) continue;
+        const f32x4* src = rd + (size_t)s2 * NWAVES * F * 64;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if (i < oi_lo || i >= oi_hi || j < oj_lo || j >= oj_hi) continue;
+            acc[i][j] += __builtin_nontemporal_load(src + (i * NJ + j) * 64);
+          }
+      }
+      if constexpr ((FLAGS & FLAG_TIMED) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_rs3)::"memory");
+        if (p.trace && lane == 0) {
+          unsigned long long* t = p.trace + ((long long)blockIdx.x * NWAVES + wave) * 16;
+          t[0] = t_rs1 - t_loop1;      // write-through stores issued + drained
+          t[1] = t_rs2 - t_rs1;        // block barrier, arrival, poll for the peers, acquire, block barrier
+          t[2] = t_rs3 - t_rs2;        // peers' partials loaded and added
+          t[3] = sidx;
+        }
+      }
+      __syncthreads();                                       // every wave has consumed its peers' partials
+      if (tid == 0) {
+        const int left = __hip_atomic_fetch_add(p.sk_depart + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == S - 1) {                                 // everybody has passed the poll: clean for the next launch
+          __hip_atomic_store(p.sk_depart + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+  // Mode 0, CHAIN.  Release / acquire at agent scope, executed by ONE lane per block: the release (buffer_wbl2) walks the
   // whole L2, and one per wave made the hand-off cost ~60 us per launch.  Every wave first waits for its
   // own stores (vmcnt(0)), the block barrier collects them, then lane 0 fences and moves the counter.
-  if (S > 1) {
+  if (S > 1 && !rs) {
     f32x4* part = (f32x4*)(p.sk_part + (size_t)bid * (BM * BN)) + (size_t)wave * (MI * NJ) * 64 + lane;
     int* flag = p.sk_flag + bid;
     if (sidx > 0) {
@@ -1132,13 +1236,20 @@ void gemm_nt_kernel(const GemmParams p) {
   auto cswz = [](int c, int row) { return (NCH & (NCH - 1)) == 0 ? (c ^ (row & (NCH - 1))) : (c + row) % NCH; };
   if (wide) {
     // phase A: registers -> LDS
-    auto phase_a = [&](auto addvec_tag) {
+    // sub_tag: only the fragments this block owns after a reduce-scatter split-K hand-off (wave-uniform ranges)
+    auto phase_a = [&](auto addvec_tag, auto sub_tag) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        if constexpr (decltype(sub_tag)::value) {
+          if (i < oi_lo || i >= oi_hi) continue;
+        }
         const int row = i * 16 + r16;
         const int m = min(m0 + wm * WTM + row, Mg - 1);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
+          if constexpr (decltype(sub_tag)::value) {
+            if (j < oj_lo || j >= oj_hi) continue;
+          }
           const int n4 = min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4);
           float v[4];
           biased(addvec_tag, i, j, m, n4, v);
@@ -1150,15 +1261,33 @@ void gemm_nt_kernel(const GemmParams p) {
         }
       }
     };
-    if (p.addvec) phase_a(std::true_type{});
-    else phase_a(std::false_type{});
+    if constexpr (RS_CAPABLE) {
+      if (rs) phase_a(std::false_type{}, std::true_type{});          // (the launcher keeps addvec GEMMs on the chain)
+      else if (p.addvec) phase_a(std::true_type{}, std::false_type{});
+      else phase_a(std::false_type{}, std::false_type{});
+    } else {
+      if (p.addvec) phase_a(std::true_type{}, std::false_type{});
+      else phase_a(std::false_type{}, std::false_type{});
+    }
     if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_epiA)::"memory");
     // phase B: LDS -> 8 consecutive columns per lane -> global
     constexpr int NIT = (WTM * NCH + 63) / 64;
+    // reduce-scatter split-K: the owned rows [r_lo, r_lo + nr) x chunks [c_lo, c_lo + ncw) of the wave's sub-tile only
+    const int r_lo = oi_lo * 16, nr = (oi_hi - oi_lo) * 16, c_lo = oj_lo * 2, ncw = (oj_hi - oj_lo) * 2;
+    const int nit = rs ? (nr * ncw + 63) >> 6 : NIT;
 #pragma unroll 4
-    for (int t = 0; t < NIT; ++t) {
+    for (int t = 0; t < nit; ++t) {
       const int idx = t * 64 + lane;
-      const int row = idx / NCH, c = idx - row * NCH;
+      int row, c;
+      if (RS_CAPABLE && rs) {
+        const int rr = (int)((unsigned)idx / (unsigned)ncw);
+        row = r_lo + rr;
+        c = c_lo + idx - rr * ncw;
+        if (rr >= nr) continue;
+      } else {
+        row = idx / NCH;
+        c = idx - row * NCH;
+      }
       const int m = m0 + wm * WTM + row, n8 = n0 + wn * WTN + c * 8;
       if (row >= WTM || m >= Mg || n8 >= N) continue;
       const u32x4 x = *(const u32x4*)(my_lds + row * (NCH * 16) + cswz(c, row) * 16);
@@ -1209,7 +1338,7 @@ void gemm_nt_kernel(const GemmParams p) {
     asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_epiB)::"memory");
     asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t_end), "=s"(rt_end)::"memory");
     if (p.trace && lane == 0) {
-      unsigned long long* t = p.trace + ((long long)bid * NWAVES + wave) * 16;
+      unsigned long long* t = p.trace + ((long long)blockIdx.x * NWAVES + wave) * 16;
       t[8] = t_end - t_start;        // whole wave, shader cycles
       t[9] = rt_end - rt_start;      // whole wave, 100 MHz ticks
       t[10] = t_loop0 - t_start;     // address setup

@@ -526,7 +526,7 @@ class Flux:
         self.run_plan(ws)
         return ws["pred"].clone()
 
-    def profile_plan(self, ws: dict) -> list:
+    def profile_plan(self, ws: dict, with_shape: bool = False) -> list:
         """Run the plan eagerly with a HIP event pair around every launch (events are recorded on the
         stream the kernels are launched on).  Returns [(kernel label, ms, flops)] in launch order;
         GEMM labels carry the tile configuration the library selected."""
@@ -545,6 +545,8 @@ class Flux:
                 flops = 2.0 * m_total * d.N * d.K
                 code = lib.fluxhip_gemm_tile_cfg(args[0])      # tile cfg | split-K factor << 8
                 label = f"fluxhip_gemm_bf16/cfg{code & 255}" + (f"s{code >> 8}" if (code >> 8) > 1 else "")
+                if with_shape:
+                    label += f" N{d.N} K{d.K}"
             elif fn.__name__ == "fluxhip_gemm_fp8":
                 d = args[0]._obj
                 m_total = sum(d.g[i].M for i in range(d.ngroups)) * d.nbatch

@@ -89,6 +89,13 @@ int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads);
  * A forced tile_cfg may carry the split factor in bits 8+ (cfg | splits << 8); fluxhip_gemm_tile_cfg reports the
  * same encoding. */
 int fluxhip_set_workspace(void* ws, int64_t bytes);
+/* Split-K hand-off mode.  0 (default): "reduce-scatter" wherever a launch allows it — a ping-pong bf16 tile whose whole
+ * split grid is resident at once (tiles x splits <= CUs): the S blocks of a tile exchange write-through partials
+ * concurrently and each finishes 1/S of the tile; everything else uses the chain (block s adds the partial of block s-1).
+ * 1: chain only (diagnostics, A/B timing).  Both are deterministic; they differ in fp32 summation order.
+ * fluxhip_gemm_rs_launches: number of reduce-scatter launches issued so far by this process (tests, profiling). */
+int fluxhip_gemm_set_splitk_mode(int mode);
+int64_t fluxhip_gemm_rs_launches(void);
 /* Diagnostic: device buffer of [blocks][waves][16] u64 that the phase-timed tile configurations fill with
  * summed s_memtime deltas per main-loop phase (7 phases, iteration count, whole-wave cycles and 100 MHz ticks, setup and epilogue cycles); NULL disables. */
 int fluxhip_gemm_set_trace(void* buf);

@@ -118,6 +118,101 @@ def test_gemm_split_k_no_stale_partials(dev, cfg, S):
     assert rel_l2(first[0], O.linear(xs[0].float().cpu(), w.float().cpu(), None)) < TOL
 
 
+def _rs_launches():
+    from flux_generator_amd import _lib
+    return int(_lib.load().fluxhip_gemm_rs_launches())
+
+
+@pytest.mark.parametrize("cfg,S", [(49, 2), (49, 4), (50, 2), (50, 4), (51, 2), (51, 3), (51, 4), (52, 2), (52, 4), (53, 2), (53, 4),
+                                   (54, 2), (54, 4), (55, 2), (55, 4)])
+def test_gemm_split_k_reduce_scatter(dev, cfg, S):
+    """The reduce-scatter split-K hand-off (ping-pong tiles, whole grid resident): every supported (tile, S) — ownership by
+    fragment rows (MI % S == 0) or by fragment columns (256 x 192 with S = 3) — with ragged M / N edges and the fused
+    epilogues that the Flux plan runs through it; the launch must really take the reduce-scatter path, agree with the chain
+    hand-off up to fp32 summation order, be repeatable bit for bit and leave the counters clean."""
+    from flux_generator_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = 600, 520, 1024
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    res, gate = rnd(M, N, seed=4), rnd(N, seed=5)
+    lin = O.linear(x.float().cpu(), w.float().cpu(), b.float().cpu())
+    code = cfg | (S << 8)
+    n0 = _rs_launches()
+    outs = [ops.linear(x, w, b, epi=ops.EPI_GATE_RES, res=res, gate=gate, tile_cfg=code) for _ in range(3)]
+    assert _rs_launches() == n0 + 3, "the launch did not use the reduce-scatter hand-off"
+    assert rel_l2(outs[0], res.float().cpu() + gate.float().cpu() * lin) < TOL
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert rel_l2(ops.linear(x, w, b, tile_cfg=code), lin) < TOL
+    assert rel_l2(ops.linear(x, w, b, epi=ops.EPI_GELU_TANH, tile_cfg=code), O.gelu_tanh(lin)) < TOL
+    assert lib.fluxhip_gemm_set_splitk_mode(1) == 0
+    try:
+        n1 = _rs_launches()
+        chain = ops.linear(x, w, b, epi=ops.EPI_GATE_RES, res=res, gate=gate, tile_cfg=code)
+        assert _rs_launches() == n1
+    finally:
+        assert lib.fluxhip_gemm_set_splitk_mode(0) == 0
+    assert rel_l2(outs[0], chain.float().cpu()) < 4e-3
+    again = ops.linear(x, w, b, epi=ops.EPI_GATE_RES, res=res, gate=gate, tile_cfg=code)      # counters were left clean
+    assert torch.equal(again, outs[0])
+
+
+def test_gemm_split_k_reduce_scatter_under_uneven_load(dev):
+    """The S blocks of a tile wait for EACH OTHER: run the Flux shapes (linear2: 1280 x 3072 x 15360, S = 3, 240 blocks) while a
+    second stream keeps taking CUs and memory bandwidth away (blocks of one tile then start far apart), alternating two
+    problems through the same workspace so that a consumer's L1 / L2 hold the PREVIOUS launch's slab lines.  Every result
+    must equal its first, bit for bit, 30 launches long."""
+    from flux_generator_amd import ops
+    M, N, K = 1280, 3072, 15360
+    xs = [rnd(M, K, seed=s) for s in (1, 2)]
+    w = rnd(N, K, seed=3, scale=K ** -0.5)
+    res = rnd(M, N, seed=4)
+    n0 = _rs_launches()
+    first = [ops.linear(x, w, None, epi=ops.EPI_GATE_RES, res=res).clone() for x in xs]
+    assert _rs_launches() == n0 + 2, "the picker did not choose a reduce-scatter split for linear2 at batch 1"
+    assert rel_l2(first[0], res.float().cpu() + O.linear(xs[0].float().cpu(), w.float().cpu(), None)) < TOL
+    side = torch.cuda.Stream(device=dev)
+    big = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    a, bmat = rnd(4096, 4096, seed=7), rnd(4096, 4096, seed=8)
+    for it in range(30):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                     # competing work: a copy kernel and a plain GEMM, varying per iteration
+            if it % 3 != 1:
+                big[: (64 + 32 * (it % 5)) << 20].add_(1)
+            if it % 2:
+                ops.linear(a, bmat, None)
+        y = ops.linear(xs[it & 1], w, None, epi=ops.EPI_GATE_RES, res=res)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(y, first[it & 1]), f"iteration {it}"
+
+
+def test_gemm_split_k_reduce_scatter_grouped_batched(dev):
+    """Reduce-scatter split-K under the 2-group (txt / img), batched launch shape of the double blocks' mlp2 with per-batch
+    gates, forced onto 256 x 256 tiles with S = 4 (ownership by fragment rows)."""
+    from flux_generator_amd import ops
+    B, S_, L, D, N = 2, 256, 256, 2048, 512
+    T = S_ + L
+    x = rnd(B, T, D, seed=1)
+    wt, wi = rnd(N, D, seed=2, scale=D ** -0.5), rnd(N, D, seed=3, scale=D ** -0.5)
+    bt, bi = rnd(N, seed=4), rnd(N, seed=5)
+    res = rnd(B, T, N, seed=6)
+    gates = rnd(B, 2 * N, seed=7)
+    out = torch.empty(B, T, N, dtype=BF, device=dev)
+    e = 2
+    gs = [dict(A=x.data_ptr(), W=wt.data_ptr(), bias=bt.data_ptr(), C=out.data_ptr(), res=res.data_ptr(), gate=gates.data_ptr(),
+               gate_bstride=2 * N, a_bstride=T * D, c_bstride=T * N, M=S_),
+          dict(A=x.data_ptr() + S_ * D * e, W=wi.data_ptr(), bias=bi.data_ptr(), C=out.data_ptr() + S_ * N * e,
+               res=res.data_ptr() + S_ * N * e, gate=gates.data_ptr() + N * e, gate_bstride=2 * N, a_bstride=T * D,
+               c_bstride=T * N, M=L)]
+    n0 = _rs_launches()
+    ops.gemm(ops.make_gemm_desc(gs, B, N, D, D, N, ops.EPI_GATE_RES, tile_cfg=49 | (4 << 8)))
+    assert _rs_launches() == n0 + 1
+    xf, rf, gf = x.float().cpu(), res.float().cpu(), gates.float().cpu()
+    ref = torch.empty(B, T, N)
+    ref[:, :S_] = rf[:, :S_] + gf[:, None, :N] * O.linear(xf[:, :S_], wt.float().cpu(), bt.float().cpu())
+    ref[:, S_:] = rf[:, S_:] + gf[:, None, N:] * O.linear(xf[:, S_:], wi.float().cpu(), bi.float().cpu())
+    assert rel_l2(out, ref) < TOL
+
+
 def test_gemm_split_k_oversubscribed(dev):
     """More split-K blocks than the chip can hold at once: consumers only ever wait for lower block ids."""
     from flux_generator_amd import ops
