@@ -10,7 +10,8 @@ requirements.txt:2 — unpinned, not vendored, not importable in this image) and
 reference's own tests holds a numeric golden for this path.  The restatement
 is therefore pinned only by (1) hand-derived known answers (tests/test_oracle_kat.py), (2)
 agreement with independent torch.nn.functional implementations of each op, and (3) golden vectors
-generated *by this oracle* (tests/golden/, script tests/golden/make_golden.py).
+generated *by this oracle* (tests/golden/, script tests/golden/make_golden.py).  The MLX facts it assumes, what
+pins each of them here and what an MLX run could still contradict are listed in oracle/UNVERIFIED.md.
 
 Every function cites the reference lines it follows (paths relative to the reference tree).
 All functions are dtype-generic: run them in float32 for the "exact" answer, or in bfloat16 to

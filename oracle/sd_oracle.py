@@ -119,15 +119,18 @@ class EulerAncestralSampler(EulerSampler):
     """SimpleEulerAncestralSampler.step (sampler.py:88-105). The fresh N(0,1) draw is an input here
     (MLX's RNG stream cannot be reproduced; parity is defined on identical noise)."""
 
-    def coefficients(self, t, t_prev):
-        sigma, sigma_prev = self.sigmas(t), self.sigmas(t_prev)
+    def coefficients(self, t, t_prev, dtype=torch.float32):
+        """sigma and sigma_prev are cast to the eps dtype FIRST (sampler.py:90-91) and everything derived from them
+        (sigma^2, sigma_up, sigma_down) is then evaluated in that dtype (sampler.py:93-96): irrelevant in float32,
+        visible in float16 (the reference's UNet dtype), where e.g. sigma^2 = 213.6 rounds to an 11-bit mantissa."""
+        sigma, sigma_prev = self.sigmas(t).to(dtype), self.sigmas(t_prev).to(dtype)
         sigma2, sigma_prev2 = sigma.square(), sigma_prev.square()
         sigma_up = (sigma_prev2 * (sigma2 - sigma_prev2) / sigma2).sqrt()
         sigma_down = (sigma_prev2 - sigma_up ** 2).sqrt()
         return sigma, sigma_prev, sigma_up, sigma_down
 
     def step(self, eps_pred, x_t, t, t_prev, noise=None):
-        sigma, sigma_prev, sigma_up, sigma_down = [v.to(eps_pred.dtype) for v in self.coefficients(t, t_prev)]
+        sigma, sigma_prev, sigma_up, sigma_down = self.coefficients(t, t_prev, eps_pred.dtype)
         dt = sigma_down - sigma
         x = (sigma.square() + 1).sqrt() * x_t + eps_pred * dt
         x = x + noise.to(x.dtype) * sigma_up

@@ -159,6 +159,49 @@ def test_flux_block_vs_independent_module():
     assert rel_l2(got, x + gate * y) < 1e-5
 
 
+def test_double_block_full_width_vs_independent_module():
+    """One DoubleStreamBlock at Flux's real width (3072 wide, 24 heads of 128, MLP 12288; flux/layers.py:181-231) written
+    a second time with torch.nn.functional ops and the COMPLEX-number form of RoPE (the oracle uses the reference's
+    2x2 rotation-matrix form, flux/layers.py:9-33), txt rows at position (0, 0, 0), img rows on a 2-D grid."""
+    g = torch.Generator().manual_seed(4)
+    D, H, S, L = 3072, 24, 8, 24
+    P = O.FluxParams(depth=1, depth_single_blocks=0)
+    W = O.init_weights({k: v for k, v in O.flux_weight_shapes(P).items() if k.startswith("double_blocks.0")}, seed=5,
+                       norm_jitter=0.3)
+    img, txt, vec = torch.randn(1, L, D, generator=g), torch.randn(1, S, D, generator=g), torch.randn(1, D, generator=g)
+    ids = torch.zeros(1, S + L, 3, dtype=torch.int32)
+    ids[0, S:, 1] = torch.arange(L) // 6
+    ids[0, S:, 2] = torch.arange(L) % 6
+    pe = O.embed_nd(ids, [16, 56, 56], 10000)
+    gi, gt = O.double_stream_block(W, "double_blocks.0", H, img, txt, vec, pe)
+
+    p, hd = "double_blocks.0", D // H
+    lin = lambda x, n: F.linear(x, W[f"{p}.{n}.weight"], W[f"{p}.{n}.bias"])                          # noqa: E731
+    rn = lambda t, w: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5) * w                       # noqa: E731
+    mods = {st: lin(F.silu(vec), f"{st}_mod.lin")[:, None].chunk(6, dim=-1) for st in ("img", "txt")}
+    qkv = {}
+    for st, x in (("txt", txt), ("img", img)):
+        sh, sc = mods[st][0], mods[st][1]
+        o = lin((1 + sc) * F.layer_norm(x, (D,), eps=1e-6) + sh, f"{st}_attn.qkv")
+        q, k, v = (t.view(1, -1, H, hd).transpose(1, 2) for t in o.chunk(3, dim=-1))
+        qkv[st] = (rn(q, W[f"{p}.{st}_attn.norm.query_norm.weight"]), rn(k, W[f"{p}.{st}_attn.norm.key_norm.weight"]), v)
+    q, k, v = (torch.cat([qkv["txt"][i], qkv["img"][i]], dim=2) for i in range(3))
+    ang = torch.cat([ids[..., i:i + 1].float() * (1.0 / (10000 ** (torch.arange(0, d, 2).float() / d)))
+                     for i, d in enumerate([16, 56, 56])], dim=-1)
+    rot = torch.polar(torch.ones_like(ang), ang)[:, None]
+    T = S + L
+    cr = lambda t: torch.view_as_real(torch.view_as_complex(t.reshape(1, H, T, hd // 2, 2).contiguous()) * rot).reshape(1, H, T, hd)  # noqa: E731
+    a = F.scaled_dot_product_attention(cr(q), cr(k), v).transpose(1, 2).reshape(1, T, D)
+    outs = {}
+    for st, x, att in (("txt", txt, a[:, :S]), ("img", img, a[:, S:])):
+        _, _, g1, s2, c2, g2 = mods[st]
+        x = x + g1 * lin(att, f"{st}_attn.proj")
+        h = lin(F.gelu(lin((1 + c2) * F.layer_norm(x, (D,), eps=1e-6) + s2, f"{st}_mlp.layers.0"), approximate="tanh"),
+                f"{st}_mlp.layers.2")
+        outs[st] = x + g2 * h
+    assert rel_l2(gi, outs["img"]) < 1e-5 and rel_l2(gt, outs["txt"]) < 1e-5
+
+
 # ---------------------------------------------------------------- 4. committed golden vectors
 @pytest.mark.parametrize("name", ["flux_tiny_schnell", "flux_tiny_dev", "vae_tiny"])
 def test_golden_vectors(name):

@@ -37,6 +37,36 @@ def test_euler_steps_formulas():
     assert torch.allclose(a.step(e, x, t, tp, n), want, atol=1e-5)
 
 
+def test_ancestral_step_float16_cast_order():
+    """The reference runs the UNet (and therefore the sampler arithmetic) in float16: sigma and sigma_prev are cast to the
+    eps dtype first and sigma^2, sigma_up, sigma_down are float16 expressions of those (sampler.py:88-105).  An independent
+    numpy float16 evaluation of exactly that sequence, op by op, must match the oracle's float16 run bit for bit, and it
+    must DIFFER from evaluating the coefficients in float32 and casting afterwards (what the oracle did before)."""
+    import numpy as np
+    a = S.EulerAncestralSampler(S.DiffusionConfig())
+    g = torch.Generator().manual_seed(3)
+    x, e, n = (torch.randn(64, generator=g).half() for _ in range(3))
+    differs = 0
+    for t, tp in [(1000.0, 750.0), (750.0, 500.0), (500.0, 250.0), (999.0, 333.0)]:
+        h = np.float16
+        sg, sp = h(float(a.sigmas(t))), h(float(a.sigmas(tp)))
+        sg2, sp2 = h(sg * sg), h(sp * sp)
+        up = h(np.sqrt(h(h(sp2 * h(sg2 - sp2)) / sg2)))
+        down = h(np.sqrt(h(sp2 - h(up * up))))
+        dt = h(down - sg)
+        xn, en, nn_ = x.numpy(), e.numpy(), n.numpy()
+        y = (h(np.sqrt(h(sg2 + h(1)))) * xn).astype(h) + (en * dt).astype(h)
+        y = (y + (nn_ * up).astype(h)).astype(h)
+        want = (y * h(h(1) / np.sqrt(h(sp2 + h(1))))).astype(h)
+        got = a.step(e, x, t, tp, n)
+        assert got.dtype == torch.float16
+        # torch.rsqrt in half is evaluated in float and rounded once; numpy's 1/sqrt above rounds twice: allow 1 ulp there
+        assert np.max(np.abs(got.numpy().astype(np.float32) - want.astype(np.float32))) <= 2 * float(np.spacing(h(np.max(np.abs(want)))))
+        _, _, up32, down32 = a.coefficients(t, tp, torch.float32)
+        differs += int(float(up32.half()) != float(up) or float(down32.half()) != float(down))
+    assert differs > 0, "float16-first and float32-then-cast coefficients never differ: the test does not exercise the cast order"
+
+
 def test_sinusoidal_matches_diffusers_timesteps():
     """== diffusers Timesteps(flip_sin_to_cos=True, downscale_freq_shift=0): 10000^(-i/half)."""
     t = torch.tensor([999.0, 1.0])
