@@ -62,6 +62,7 @@ SIGNATURES = {
     "fluxhip_gemm_tile_shape": (c_int, [c_int, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),
     "fluxhip_gemm_set_trace": (c_int, [c_void_p]),
     "fluxhip_gemm_set_splitk_mode": (c_int, [c_int]),
+    "fluxhip_attention_set_variant": (c_int, [c_int]),
     "fluxhip_gemm_rs_launches": (C.c_int64, []),
     "fluxhip_set_workspace": (c_int, [c_void_p, c_int64]),
     "fluxhip_conv2d_bf16": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_void_p]),

@@ -37,6 +37,7 @@ struct AttnParams {
   float scale_log2;
   float scale;              // MODE 1: logits = scale * q.k + bias
   const bf16_t* bias;       // MODE 1: additive bias [H][Tq][Tk] (T5 relative position bias)
+  int force_slow;           // attn128_w64_kernel: take the online-rescale fallback (tests)
 };
 
 // MODE 0: plain; MODE 1: additive per-head bias (flux/t5.py:70-116,153-155: scale 1.0, bias passed as
@@ -368,6 +369,442 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
 }
 
 
+// -------------------------------------------------------------------------------------------------------------------
+// head_dim 128, 64 QUERIES PER WAVE, one wave per SIMD, software-pipelined by program order (round 3).
+// Same transposed products, LDS-DMA staging, swizzles and key-permuted V^T layout as attn_kernel above; what changes is the
+// work per wave and who overlaps with whom.  r02 counters of attn_kernel at T = 1280: matrix pipe busy 26 %, the MFMA and
+// VALU instruction classes hardly overlapping — two lock-stepped waves per SIMD, each a serial chain S -> softmax -> PV.
+//  * a wave owns TWO 32-query blocks (A, B) and the whole 512-entry register file of its SIMD (4 waves per workgroup,
+//    __launch_bounds__(256, 1)), and overlaps their chains IN PROGRAM ORDER — an in-order wave only overlaps what is
+//    interleaved instruction by instruction, so every MFMA of a phase is followed by one slice of the other block's work:
+//        phase 1   S_A            16 MFMAs   | K fragment reads (8 ahead), LDS-DMA pieces of the next stage
+//        phase 2   S_B            16 MFMAs   | softmax_A in 16 slices, K re-reads, V^T fragment reads
+//        -- lgkmcnt(0), vmcnt(0), barrier: this stage's LDS buffer is dead, the next stage is visible --
+//        phase 3   PV_A           16 MFMAs   | softmax_B in 16 slices
+//        phase 4   PV_B           16 MFMAs   | first 8 K fragments of this wave's NEXT tile
+//    V^T fragments (64 registers) are read once and feed both blocks; K fragments go through an 8-deep register ring and
+//    are read twice (the LDS has the bandwidth, the arch VGPRs do not have the room for all 16).
+//  * register classes are pinned with inline-asm MFMAs (hipcc, left alone, parks the S accumulators in AccVGPRs and moves
+//    hundreds of registers per tile across the files): S accumulators / P in arch VGPRs (the softmax is VALU work), O^T
+//    accumulators (128 registers) and Q^T fragments (64) in AccVGPRs.  An asm MFMA is opaque to hipcc's hazard recogniser:
+//    the required wait states (MFMA result -> VALU read, VALU write -> MFMA operand) are s_nop's inside the asm strings.
+//  * no O rescale in the loop: VALU code touching the O accumulators makes hipcc carry them in arch VGPRs (128 copies per
+//    tile).  Softmax is shift-invariant, so the reference of a query is simply the row maximum of its FIRST tile and never
+//    moves; exp2 then overflows only if a later score exceeds it by > ~100 in the log2 domain (a raw logit gap of ~800 at
+//    head_dim 128).  That case is DETECTED (sticky flag, block-wide OR through LDS) and the workgroup recomputes its queries
+//    with the plain online-rescale loop (`slow`, compiler-scheduled): correct for any input, never taken on sane logits.
+//  * KS = 2 (small grids, e.g. batch 1 at 512 x 512: 24 heads x 10 blocks of 128 queries = 240 workgroups): waves 0-1 take
+//    the even KV tiles of the workgroup's 128 queries, waves 2-3 the odd ones, merged through LDS at the end.  KS = 1:
+//    256 queries per workgroup.
+DEVINL void mfma_s0(f32x16& acc, const bf16x8& a, const bf16x8& b) {     // first MFMA of a chain: C = 0
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
+}
+DEVINL void mfma_s(f32x16& acc, const bf16x8& a, const bf16x8& b) {      // acc: arch VGPRs; b (Q^T fragment): AccVGPRs
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
+DEVINL void mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {      // acc (O^T): AccVGPRs; b = freshly packed P
+  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// max without the canonicalising v_max x, x that fmaxf() puts in front of values hipcc cannot prove quiet (asm MFMA outputs)
+DEVINL float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEVINL float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// MFMA result (arch VGPRs) -> first VALU read: 16-pass worst case 19 wait states (gfx940 hazard table)
+DEVINL void mfma_settle(f32x16& a, f32x16& b) { asm("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b)); }
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void attn128_w64_kernel(const AttnParams p) {
+  constexpr int HD = 128, NW = 4, NQW = NW / KS;      // query-owning waves per workgroup
+  constexpr int RB = HD * 2, KT_BYTES = KV * RB, VT_BYTES = HD * KV * 2, STAGE = KT_BYTES + VT_BYTES;
+  constexpr int NDS = HD / 16, NDB = HD / 32;
+  constexpr int NPIECE = 8 * KS;                      // LDS-DMA pieces per wave and stage (KS tiles x 32 pieces over 4 waves)
+  constexpr int FLAG_OFF = 2 * KS * STAGE;            // one LDS word after the stage buffers: block-wide overflow flag
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ql = lane & 31;
+  const int H = p.H, Tq = p.Tq, Tk = p.Tk, Tkpad = p.Tkpad;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = logical / p.nqb;
+  const int qb = logical - bh * p.nqb;
+  const int b = bh / H, h = bh - b * H;
+  // dense head-major operands (fluxhip_attention_d128_bf16): Q, K [B][H][T][128], V^T [B][H][128][Tkpad]
+  const bf16_t* Qh = p.Q + ((long long)bh * Tq) * HD;
+  const char* Kh = (const char*)(p.K + ((long long)bh * Tk) * HD);
+  const char* Vh = (const char*)(p.Vt + (long long)bh * HD * Tkpad);
+
+  const int qw = wave % NQW, kp = wave / NQW;
+  const int q0 = qb * (NQW * 64) + qw * 64;           // first query of this wave; block x covers q0 + 32 x + [0, 32)
+
+  // staging: piece id = wave + 4 i (i < NPIECE / 2 for K, then for V^T) over the KS tiles of a stage.
+  //   K piece   = 4 key rows x 16 chunks: row = 16 (i & 3) + 4 wave + (lane >> 4)  ->  row & 15 is a lane constant
+  //   V^T piece = 8 d rows x 8 chunks:    d   = 32 (i & 3) + 8 wave + (lane >> 3)  ->  (d >> 1) & 7 is a lane constant
+  const int krl = 4 * wave + (lane >> 4);
+  const uint32_t k_lane = (uint32_t)krl * RB + (uint32_t)(((lane & 15) ^ krl) << 4);            // byte offset inside 16 key rows
+  const int dl = 8 * wave + (lane >> 3);
+  const char* v_lane = Vh + (long long)dl * Tkpad * 2 + (((lane & 7) ^ ((dl >> 1) & 7)) << 4);
+  auto stage1 = [&](int st_next, int buf, int i) {     // piece i of this wave for stage st_next -> LDS buffer buf
+    char* s0 = smem + buf * (KS * STAGE);
+    const int key0 = st_next * (KS * KV);
+    if (i < NPIECE / 2) {
+      const int tile = i >> 2, sub = i & 3;
+      const int key = min(key0 + tile * KV + 16 * sub + krl, Tk - 1);       // (clamped rows are masked or never used)
+      glds16(Kh + (long long)key * RB + (k_lane - (uint32_t)krl * RB), s0 + tile * STAGE + (wave + 4 * sub) * 1024);
+    } else {
+      const int j = i - NPIECE / 2, tile = j >> 2, sub = j & 3;
+      const long long koff = min((long long)key0 + tile * KV, (long long)Tkpad - KV);
+      glds16(v_lane + (long long)(32 * sub) * Tkpad * 2 + koff * 2, s0 + tile * STAGE + KT_BYTES + (wave + 4 * sub) * 1024);
+    }
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // fragment addresses inside a tile: K: row kb * 32 + ql, chunk (2 ds + hi) ^ (ql & 15); V^T: row db * 32 + ql, chunk (4 kb + 2 j) | hi
+  uint32_t koff[NDS], voff[4];
+#pragma unroll
+  for (int ds = 0; ds < NDS; ++ds) koff[ds] = ql * RB + (((ds * 2 + hi) ^ (ql & 15)) << 4);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) voff[c] = KT_BYTES + ql * 128 + ((((2 * c) | hi) ^ ((ql >> 1) & 7)) << 4);
+
+  const int ntiles = (Tk + KV - 1) / KV;
+  const float scale_log2 = p.scale_log2;
+  const int nstages = (ntiles + KS - 1) / KS;
+
+  float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+  f32x16 oT[2][NDB];
+  bool ovf = p.force_slow != 0;
+
+  if (!ovf) {
+    // ================================================== fast path =======================================================
+    bf16x8 qf[2][NDS];                     // Q^T fragments of both query blocks (AccVGPRs: only ever MFMA B operands)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int qrow = min(q0 + 32 * x + ql, Tq - 1);
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds) qf[x][ds] = *(const bf16x8*)(Qh + (long long)qrow * HD + ds * 16 + hi * 8);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oT[x][i][r] = 0.f;
+
+    bf16x8 kw[8], vf[4][NDB];              // K fragment ring (fragment f = ds * 2 + kb sits in slot f & 7), V^T fragments [kb * 2 + j][db]
+    f32x16 sT[2][2];                       // [query block][key block]: 16 keys of query (lane & 31) per key block
+    bf16x8 pf[2][4];                       // packed P^T fragments [query block][kb * 2 + j]
+    float pm[2][4], mneg[2], psum[2], excess[2] = {0.f, 0.f};
+    auto read_k = [&](uint32_t sbase, auto fc) {          // K fragment f of the tile at sbase -> ring slot f & 7
+      constexpr int f = decltype(fc)::value & 15, ds = f >> 1, kb = f & 1;
+      bf16x8& dst = kw[f & 7];                            // (named outside the asm: operands of an asm statement inside a generic
+      const uint32_t addr = sbase + koff[ds];             //  lambda do not count as captures for clang)
+      if constexpr (kb == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(32 * RB) : "memory");
+    };
+    auto read_v = [&](uint32_t sbase, auto ic) {          // V^T fragment i = c * 4 + db
+      constexpr int i = decltype(ic)::value, c = i >> 2, db = i & 3;
+      bf16x8& dst = vf[c][db];
+      const uint32_t addr = sbase + voff[c];
+      if constexpr (db == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(db * 32 * 128) : "memory");
+    };
+    // softmax of one query block in 16 slices (one per MFMA gap of the phase it hides in)
+    auto sm_slice = [&](auto xc, auto ic, auto firstc, auto lastc, int key0) {
+      constexpr int x = decltype(xc)::value, i = decltype(ic)::value;
+      if constexpr (i < 4) {               // partial maxima over 8 scores each (key-tail mask first: last stage only)
+        constexpr int kb = i >> 1, r0 = (i & 1) * 8;
+        if constexpr (decltype(lastc)::value) {
+          if (key0 + KV > Tk) {
+#pragma unroll
+            for (int r = r0; r < r0 + 8; ++r)
+              if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Tk) sT[x][kb][r] = -1e30f;
+          }
+        }
+        const float m0 = vmax3(sT[x][kb][r0], sT[x][kb][r0 + 1], sT[x][kb][r0 + 2]);
+        const float m1 = vmax3(sT[x][kb][r0 + 3], sT[x][kb][r0 + 4], sT[x][kb][r0 + 5]);
+        pm[x][i] = vmax3(vmax(sT[x][kb][r0 + 6], sT[x][kb][r0 + 7]), m0, m1);
+      } else if constexpr (i == 4) {       // row maximum: reference of the query (first tile) / overflow watch (later tiles)
+        const float mh = vmax(vmax(pm[x][0], pm[x][1]), vmax(pm[x][2], pm[x][3]));
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
+        const float mx = vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        if constexpr (decltype(firstc)::value) m_run[x] = mx;
+        else excess[x] = vmax(excess[x], mx - m_run[x]);       // branch-free: judged once, after the loop
+        mneg[x] = -m_run[x] * scale_log2;
+        psum[x] = 0.f;
+      } else if constexpr (i < 13) {       // 8 slices of 4 scores: p = exp2(s * scale - m)
+        constexpr int e0 = (i - 5) * 4, kb = e0 >> 4, r0 = e0 & 15;
+#pragma unroll
+        for (int r = r0; r < r0 + 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sT[x][kb][r], scale_log2, mneg[x]));
+          sT[x][kb][r] = pv;
+          psum[x] += pv;
+        }
+      } else if constexpr (i < 15) {       // pack to bf16: fragment c = kb * 2 + j holds P[kb][8 j .. 8 j + 7]
+#pragma unroll
+        for (int c = (i - 13) * 2; c < (i - 13) * 2 + 2; ++c) {
+          union { bf16x8 v; uint32_t u[4]; } t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t.u[e] = pack_bf16x2(sT[x][c >> 1][8 * (c & 1) + 2 * e], sT[x][c >> 1][8 * (c & 1) + 2 * e + 1]);
+          pf[x][c] = t.v;
+        }
+      } else {
+        l_run[x] += psum[x];
+      }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    constexpr std::integral_constant<int, 0> XA{};
+    constexpr std::integral_constant<int, 1> XB{};
+
+    // one stage of this wave: its tile `it`; FIRST: first tile of the wave, MORE: another stage follows
+    auto body = [&](int st, auto firstc, auto morec) {
+      constexpr bool MORE = decltype(morec)::value;
+      using LAST = std::integral_constant<bool, !MORE>;
+      const int cur = st & 1;
+      const int it = st * KS + kp;
+      const bool active = KS == 1 || it < ntiles;
+      const uint32_t sbase = lds0 + cur * (KS * STAGE) + kp * STAGE;
+      const uint32_t sbn = lds0 + (cur ^ 1) * (KS * STAGE) + kp * STAGE;
+      const int key0 = it * KV;
+      if (active) {
+        // ---- phase 1: S_A | K ring refills, LDS-DMA pieces of the next stage ----------------------------------------
+        static_for<0, 16>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, ds = i >> 1, kb = i & 1;
+          asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");         // fragment i has landed (7 younger reads in flight)
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (ds == 0) mfma_s0(sT[0][kb], kw[i & 7], qf[0][ds]);
+          else mfma_s(sT[0][kb], kw[i & 7], qf[0][ds]);
+          read_k(sbase, std::integral_constant<int, i + 8>{});        // i < 8: fragments 8..15; then fragments 0..7 again (S_B)
+          if constexpr (MORE && (KS == 2 || (i & 1) == 0)) stage1(st + 1, cur ^ 1, KS == 2 ? i : i >> 1);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        mfma_settle(sT[0][0], sT[0][1]);
+        // ---- phase 2: S_B | softmax_A, K re-reads (fragments 8..15), V^T fragment reads ----------------------------------
+        static_for<0, 16>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, ds = i >> 1, kb = i & 1;
+          // LDS ops younger than the read of fragment i: see the schedule above (K, then V^T, per gap)
+          constexpr int younger = i < 8 ? 7 + i : 23 - i;
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger > 15 ? 15 : younger) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (ds == 0) mfma_s0(sT[1][kb], kw[i & 7], qf[1][ds]);
+          else mfma_s(sT[1][kb], kw[i & 7], qf[1][ds]);
+          if constexpr (i < 8) read_k(sbase, std::integral_constant<int, i + 8>{});
+          read_v(sbase, ic);
+          sm_slice(XA, ic, firstc, LAST{}, key0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        mfma_settle(sT[1][0], sT[1][1]);
+      } else if constexpr (MORE) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) stage1(st + 1, cur ^ 1, i);    // idle wave set (odd tile count): just stage
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // V^T fragments are in registers:
+      wait_vm0();                                                        // ... this stage's LDS buffer is dead for this wave, and
+      __syncthreads();                                                   // after the barrier for everybody; the next stage is visible
+      if (active) {
+        // ---- phase 3: PV_A | softmax_B ----------------------------------------------------------------------------------
+        static_for<0, 16>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, c = i >> 2, db = i & 3;
+          mfma_o(oT[0][db], vf[c][db], pf[0][c]);
+          sm_slice(XB, ic, firstc, LAST{}, key0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- phase 4: PV_B | first 8 K fragments of this wave's next tile ------------------------------------------------
+        static_for<0, 16>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, c = i >> 2, db = i & 3;
+          mfma_o(oT[1][db], vf[c][db], pf[1][c]);
+          if constexpr (MORE && i < 8) read_k(sbn, ic);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    };
+
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) stage1(0, 0, i);
+    wait_vm0();
+    __syncthreads();
+    static_for<0, 8>([&](auto ic) { read_k(lds0 + kp * STAGE, ic); });
+    if (nstages == 1) {
+      body(0, T_{}, F_{});
+    } else {
+      body(0, T_{}, T_{});
+      for (int st = 1; st + 1 < nstages; ++st) body(st, F_{}, T_{});
+      body(nstages - 1, F_{}, F_{});
+    }
+    // O^T accumulators: last MFMA -> first read; outstanding K prefetches of a tile that does not exist
+    asm volatile("s_nop 15\n\ts_nop 3\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    // block-wide overflow verdict (uniform: every wave takes the same path below)
+    int* flag = (int*)(smem + FLAG_OFF);
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    ovf = vmax(excess[0], excess[1]) * scale_log2 > 100.0f;
+    if (__any(ovf) && lane == 0) atomicOr(flag, 1);
+    __syncthreads();
+    ovf = *flag != 0;
+    __syncthreads();
+  }
+
+  if (ovf) {
+    // ================================================== slow path =======================================================
+    // plain online softmax with rescale (the algorithm of attn_kernel, two query blocks per wave), compiler-scheduled
+    m_run[0] = m_run[1] = -1e30f;
+    l_run[0] = l_run[1] = 0.f;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oT[x][i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) stage1(0, 0, i);
+    wait_vm0();
+    __syncthreads();
+    for (int st = 0; st < nstages; ++st) {
+      const int cur = st & 1;
+      const int it = st * KS + kp;
+      if (st + 1 < nstages) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) stage1(st + 1, cur ^ 1, i);
+      }
+      if (KS == 1 || it < ntiles) {
+        const char* sk = smem + cur * (KS * STAGE) + kp * STAGE;
+        const int key0 = it * KV;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const int qrow = min(q0 + 32 * x + ql, Tq - 1);
+          f32x16 s2[2];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2[kb][r] = 0.f;
+#pragma unroll
+          for (int ds = 0; ds < NDS; ++ds) {
+            const bf16x8 qv = *(const bf16x8*)(Qh + (long long)qrow * HD + ds * 16 + hi * 8);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+              const bf16x8 kv = *(const bf16x8*)(sk + koff[ds] + kb * 32 * RB);
+              s2[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv, qv, s2[kb], 0, 0, 0);
+            }
+          }
+          float mx = -1e30f;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Tk) s2[kb][r] = -1e30f;
+              mx = fmaxf(mx, s2[kb][r]);
+            }
+          mx = pair32_max(mx);
+          const float m_new = fmaxf(m_run[x], mx);
+          const float alpha = __builtin_amdgcn_exp2f((m_run[x] - m_new) * scale_log2);
+          m_run[x] = m_new;
+          l_run[x] *= alpha;
+#pragma unroll
+          for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oT[x][i][r] *= alpha;
+          float ps = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float pv = __builtin_amdgcn_exp2f((s2[kb][r] - m_new) * scale_log2);
+              s2[kb][r] = pv;
+              ps += pv;
+            }
+          l_run[x] += ps;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            union { bf16x8 v; uint32_t u[4]; } t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t.u[e] = pack_bf16x2(s2[c >> 1][8 * (c & 1) + 2 * e], s2[c >> 1][8 * (c & 1) + 2 * e + 1]);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+              const bf16x8 vv = *(const bf16x8*)(sk + voff[c] + db * 32 * 128);
+              oT[x][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, t.v, oT[x][db], 0, 0, 0);
+            }
+          }
+        }
+      }
+      wait_vm0();
+      __syncthreads();
+    }
+  }
+
+  // ---- KS = 2: fold the odd-tile state into the even-tile wave of the same queries ----------------------------------
+  if (KS == 2) {
+    constexpr int NREG = 2 * (NDB * 16 + 2);
+    float* mrg = (float*)smem + (size_t)qw * NREG * 64 + lane;      // [qw][reg][lane], after the last barrier
+    if (kp == 1) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mrg[(x * (NDB * 16 + 2) + i * 16 + r) * 64] = oT[x][i][r];
+        mrg[(x * (NDB * 16 + 2) + NDB * 16) * 64] = m_run[x];
+        mrg[(x * (NDB * 16 + 2) + NDB * 16 + 1) * 64] = l_run[x];
+      }
+    }
+    __syncthreads();
+    if (kp == 1) return;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const float m_b = mrg[(x * (NDB * 16 + 2) + NDB * 16) * 64], l_b = mrg[(x * (NDB * 16 + 2) + NDB * 16 + 1) * 64];
+      const float m_new = fmaxf(m_run[x], m_b);
+      const float fa = __builtin_amdgcn_exp2f((m_run[x] - m_new) * scale_log2);
+      const float fb = __builtin_amdgcn_exp2f((m_b - m_new) * scale_log2);
+      l_run[x] = l_run[x] * fa + l_b * fb;
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oT[x][i][r] = oT[x][i][r] * fa + mrg[(x * (NDB * 16 + 2) + i * 16 + r) * 64] * fb;
+    }
+  }
+
+  // ---- finalize: O[q][d] = O^T[d][q] / l -------------------------------------------------------------------------------
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const float inv = 1.f / pair32_sum(l_run[x]);
+    const int q = q0 + 32 * x + ql;
+    if (q < Tq) {
+      bf16_t* orow = p.O + ((long long)b * Tq + q) * p.ldo + h * HD;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int d0 = db * 32 + 8 * rg + 4 * hi;
+          u32x2 o;
+          o[0] = pack_bf16x2(oT[x][db][rg * 4 + 0] * inv, oT[x][db][rg * 4 + 1] * inv);
+          o[1] = pack_bf16x2(oT[x][db][rg * 4 + 2] * inv, oT[x][db][rg * 4 + 3] * inv);
+          *(u32x2*)(orow + d0) = o;
+        }
+    }
+  }
+}
+
+// kernel variant of fluxhip_attention_d128_bf16: 0 auto; 2 / 3: attn_kernel with one / two wave sets; 4 / 5 / 6: the 64-queries-
+// per-wave kernel with 256 / 128 queries per workgroup / chosen by grid size; + 0x100: its online-rescale fallback path.
+// FLUXHIP_ATTN in the environment or fluxhip_attention_set_variant() (tools/attn_bench.py, tests).
+int g_attn_variant = [] { const char* e = getenv("FLUXHIP_ATTN"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
+
+template <int KS>
+int launch_attn128_w64(AttnParams p, int B, hipStream_t s) {
+  constexpr int lds = 2 * KS * (KV * 128 * 2 + 128 * KV * 2) + 16;      // + the overflow flag word
+  auto fn = attn128_w64_kernel<KS>;
+  p.force_slow = (g_attn_variant & 0x100) != 0;       // tests: force the online-rescale fallback
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return FLUXHIP_ELAUNCH;
+    done = true;
+  }
+  p.nqb = (p.Tq + (256 / KS) - 1) / (256 / KS);
+  hipLaunchKernelGGL(fn, dim3(B * p.H * p.nqb), dim3(256), lds, s, p);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
 template <int HD, int MODE, int KS = 1, int VP = 0>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
   constexpr int NW = 4;
@@ -399,11 +836,25 @@ extern "C" int fluxhip_attention_d128_bf16(const void* Q, const void* K, const v
   p.nqb = (T + 127) / 128;
   p.scale_log2 = scale * 1.4426950408889634f;
   // fewer workgroups than two per CU: split the KV tiles over a second wave set instead (see attn_kernel)
-  static const int variant = [] { const char* e = getenv("FLUXHIP_ATTN"); return e ? atoi(e) : 0; }();   // tuning knob (tools/attn_bench.py)
+  const int variant = g_attn_variant & 0xff;
+  if (variant == 4) return launch_attn128_w64<1>(p, B, (hipStream_t)stream);                       // 64 queries per wave, 256 per workgroup
+  if (variant == 5 && T > 2 * KV) return launch_attn128_w64<2>(p, B, (hipStream_t)stream);         // ... 128 per workgroup, two KV wave sets
+  if (variant == 6) {                                                                               // ... chosen by grid size
+    if ((long long)B * H * ((T + 255) / 256) < 256 && T > 2 * KV) return launch_attn128_w64<2>(p, B, (hipStream_t)stream);
+    return launch_attn128_w64<1>(p, B, (hipStream_t)stream);
+  }
   if (variant == 2) return launch_attn<128, 0, 1, 1>(p, B, (hipStream_t)stream);
   if (variant == 3 && T > 2 * KV) return launch_attn<128, 0, 2, 1>(p, B, (hipStream_t)stream);   // two wave sets even on large grids
   if ((long long)B * H * p.nqb < 384 && T > 2 * KV) return launch_attn<128, 0, 2, 1>(p, B, (hipStream_t)stream);
+  // (the 64-queries-per-wave kernel, variants 4 - 6, stays opt-in: interleaved A/B runs of tools/attn_bench.py put it within
+  //  +-4 % of attn_kernel on every Flux shape — 257 vs 263 us at T = 4352, 273 vs 283 at T = 4608, 945 vs 921 at B = 4 —
+  //  both are bound by instruction issue, ~13 non-MFMA instructions per MFMA in its S phases)
   return launch_attn<128, 0, 1, 1>(p, B, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_attention_set_variant(int v) {
+  g_attn_variant = v;
+  return FLUXHIP_OK;
 }
 
 extern "C" int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,

@@ -158,6 +158,8 @@ int fluxhip_qk_norm_rope_bf16(const void* qkv, int ld, int B, int T, int S, int 
  * fluxhip_qk_norm_rope_bf16 writes (see there). */
 int fluxhip_attention_d128_bf16(const void* Q, const void* K, const void* Vt, void* O, int ldo,
                                 int B, int H, int T, int Tpad, float scale, void* stream);
+/* Diagnostic / tests: kernel variant of fluxhip_attention_d128_bf16 (0 = automatic; see csrc/attention.hip). */
+int fluxhip_attention_set_variant(int variant);
 
 /* timestep_embedding(t, dim) (flux/layers.py:46-57) for a bf16 timestep vector t[B]:
  * out[b] = [cos(a) | sin(a)], a = bf16(time_factor * t[b]) * exp(-ln(max_period) * k / (dim/2)). */

@@ -366,6 +366,58 @@ def test_qk_norm_rope_vt(dev, T, S):
 
 
 # ------------------------------------------------------------------ attention
+
+@pytest.mark.parametrize("variant", [4, 5, 0x104, 0x105])
+@pytest.mark.parametrize("B,H,T", [(1, 2, 128), (2, 3, 200), (1, 2, 65), (1, 2, 192), (1, 24, 1280), (1, 3, 1000), (2, 2, 577)])
+def test_attention_d128_w64_variants(dev, variant, B, H, T):
+    """The 64-queries-per-wave head_dim-128 kernel (csrc/attention.hip, attn128_w64_kernel): 256 (variant 4) and 128
+    (variant 5, two KV wave sets merged through LDS) queries per workgroup, ragged query / key tails, odd tile counts — and
+    its online-rescale fallback path forced on (+ 0x100) — against the float32 oracle attention on the same inputs."""
+    from flux_generator_amd import _lib, ops
+    lib = _lib.load()
+    q, k, v = rnd(B, H, T, 128, seed=1), rnd(B, H, T, 128, seed=2), rnd(B, H, T, 128, seed=3)
+    Tp = (T + 63) // 64 * 64
+    vt = torch.zeros(B, H, 128, Tp, dtype=BF, device=dev)
+    vt[..., :T] = v.transpose(-1, -2)
+    vt = vt[..., ops.vt_key_permutation(Tp, dev)].contiguous()
+    o = torch.full((B, T, H * 128), 7.0, dtype=BF, device=dev)
+    assert lib.fluxhip_attention_set_variant(variant) == 0
+    try:
+        ops.attention_d128(q, k, vt, o, H * 128, B, H, T, Tp, 128 ** -0.5)
+        torch.cuda.synchronize()
+    finally:
+        lib.fluxhip_attention_set_variant(0)
+    ref = O.sdpa(q.float().cpu(), k.float().cpu(), v.float().cpu(), 128 ** -0.5).transpose(1, 2).reshape(B, T, H * 128)
+    assert rel_l2(o, ref) < 6e-3
+
+
+def test_attention_d128_w64_overflow_falls_back(dev):
+    """The fast path of attn128_w64_kernel keeps each query's softmax reference at the row maximum of its FIRST KV tile; a
+    later logit more than ~100 (log2 domain) above it would overflow exp2, so the kernel must notice and recompute the
+    workgroup with the online-rescale loop.  Spiked keys late in the sequence (raw q.k ~ +1500 over everything before) force
+    exactly that: the result must match the oracle, where a missed overflow gives inf / NaN."""
+    from flux_generator_amd import _lib, ops
+    lib = _lib.load()
+    B, H, T = 1, 2, 640
+    q, k, v = rnd(B, H, T, 128, seed=4), rnd(B, H, T, 128, seed=5), rnd(B, H, T, 128, seed=6)
+    k[0, 0, 500] = q[0, 0, 17] * 1.5              # query 17 of head 0 meets a key aligned with it in tile 7
+    k[0, 1, 300] = q[0, 1, 200] * 1.2
+    Tp = (T + 63) // 64 * 64
+    vt = torch.zeros(B, H, 128, Tp, dtype=BF, device=dev)
+    vt[..., :T] = v.transpose(-1, -2)
+    vt = vt[..., ops.vt_key_permutation(Tp, dev)].contiguous()
+    ref = O.sdpa(q.float().cpu(), k.float().cpu(), v.float().cpu(), 1.0).transpose(1, 2).reshape(B, T, H * 128)
+    for variant in (4, 5):
+        o = torch.zeros(B, T, H * 128, dtype=BF, device=dev)
+        assert lib.fluxhip_attention_set_variant(variant) == 0
+        try:
+            ops.attention_d128(q, k, vt, o, H * 128, B, H, T, Tp, 1.0)     # scale 1: logits of +-30 ordinarily, ~190 / ~150 at the spikes
+            torch.cuda.synchronize()
+        finally:
+            lib.fluxhip_attention_set_variant(0)
+        assert bool(torch.isfinite(o.float()).all()) and rel_l2(o, ref) < 6e-3
+
+
 @pytest.mark.parametrize("B,H,T", [(1, 2, 128), (2, 3, 200), (1, 1, 1280), (1, 2, 65), (1, 2, 192), (1, 24, 1280), (2, 48, 512)])   # last: 384 workgroups -> single wave set; 192/200/1280: KV tiles split over two wave sets
 def test_attention(dev, B, H, T):
     from flux_generator_amd import ops

@@ -4,7 +4,7 @@ process, so this script re-executes itself per configuration).  TUNE_X3=1: the f
 (FLUXHIP_CONV_X3_CFG; reported TFLOP/s count the 3 MFMA passes)."""
 import os, sys, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHAPES = [(64, 512, 512, False), (64, 512, 512, True), (128, 512, 512, False), (128, 512, 512, True), (256, 512, 256, False),
+SHAPES = [(512, 128, 128, False), (512, 256, 128, False), (64, 512, 512, False), (64, 512, 512, True), (128, 512, 512, False), (128, 512, 512, True), (256, 512, 256, False),
           (256, 256, 256, False), (256, 256, 256, True), (512, 256, 128, False), (512, 128, 128, False)]
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import torch
