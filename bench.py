@@ -80,7 +80,7 @@ def pmc_traffic(label: str) -> dict:
     (tools/profile_round.sh -> tools/pmc_summary.py; counters cannot be read from inside this process).
     null when the summary has no row for this kernel."""
     import csv, re
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc.csv")
+    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic_pmc.csv")
     m = re.search(r"cfg(\d+)", label)
     if not m or "fp8" in label or not os.path.exists(path):
         return {"traffic": None}
@@ -99,7 +99,7 @@ def pmc_traffic(label: str) -> dict:
     if best is None:
         return {"traffic": None}
     return {"traffic": float(best["avg_total_MB"]) * 1e6, "traffic_unit": "HBM+MALL bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-            "traffic_source": f"profiles/r02_hbm_traffic_pmc.csv: {best['kernel']}"}
+            "traffic_source": f"profiles/r03_hbm_traffic_pmc.csv: {best['kernel']}"}
 
 
 def relaunch_under_torchrun(n: int) -> int:
