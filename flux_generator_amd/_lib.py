@@ -145,7 +145,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fluxhip_abi_version() != 3:
+    if lib.fluxhip_abi_version() != 4:
         raise RuntimeError("libfluxhip ABI version mismatch")
     if lib.fluxhip_arch() != b"gfx950":
         raise RuntimeError("libfluxhip was not built for gfx950")

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define FLUXHIP_ABI_VERSION 3
+#define FLUXHIP_ABI_VERSION 4
 
 int fluxhip_abi_version(void);
 /* "gfx950" — the only architecture this library is built for. */
