@@ -200,6 +200,7 @@ def main() -> None:
     # BENCH_FORCE_DIST=1: create the RCCL process group even at world size 1, so a single-GPU box runs exactly the
     # broadcast / barrier / max-reduce / gather code an 8-GPU launch runs
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -207,8 +208,16 @@ def main() -> None:
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # BENCH_SHARE_GPU=1 (diagnostic, single-GPU boxes): every rank uses cuda:0 and the collectives go over gloo (RCCL refuses
+        # two ranks on one device).  Exercises the N-rank launch, sharding, barrier / max-reduce and gather with real kernels;
+        # the throughput of such a run is NOT a scaling number (the ranks time-share one GPU) and the JSON says so.
+        if share_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -268,7 +277,7 @@ def main() -> None:
     per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if share_gpu else dev, dtype=torch.float64)
         every = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(every, tt)
         per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
@@ -354,7 +363,8 @@ def main() -> None:
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms), "ranks": per_rank_ms},
-            "collectives": (f"RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())} (torch.distributed nccl backend)" if use_dist else None),
+            "collectives": (("gloo; ALL RANKS SHARE ONE GPU (BENCH_SHARE_GPU diagnostic): not a scaling measurement" if share_gpu else
+                             f"RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())} (torch.distributed nccl backend)") if use_dist else None),
             "dtype": "fp8 e4m3 (block Linears: weights per-channel, activations per-token; residual stream / attention / VAE as in bf16 mode)" if args.fp8 else "bf16",
             "data": "synthetic",
             "config": {"workload": f"{args.model.replace('flux-', 'Flux-')} {args.image_size}x{args.image_size} {args.denoise_steps}-step, "

@@ -32,6 +32,22 @@ def active() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def _host_staged() -> bool:
+    """gloo carries host memory only (it is the backend of the CPU tests and of the two-ranks-on-one-GPU test): device
+    tensors are staged through the host there.  RCCL ("nccl") moves device memory directly over xGMI."""
+    return dist.get_backend() == "gloo"
+
+
+def _broadcast(t: torch.Tensor, src: int) -> None:
+    """In-place broadcast of a contiguous tensor."""
+    if t.is_cuda and _host_staged():
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
 def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous, balanced split of n images: the first n % W ranks take one extra."""
     q, r = divmod(n, world_size)
@@ -50,7 +66,7 @@ def broadcast_conditioning(txt: Optional[torch.Tensor], vec: Optional[torch.Tens
         vec = torch.empty(shapes[1], dtype=dtype, device=device)
     # bf16 / int16 are not supported by every gloo build: ship the raw bytes
     for t in (txt, vec):
-        dist.broadcast(t.view(torch.uint8), src=src)
+        _broadcast(t.view(torch.uint8), src)
     return txt, vec
 
 
@@ -72,11 +88,14 @@ def gather_images(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[t
     nmax = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros((nmax, *local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
+    dev = pad.device
+    if pad.is_cuda and _host_staged():
+        pad = pad.cpu()
     bufs: Optional[List[torch.Tensor]] = [torch.empty_like(pad) for _ in range(W)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0).to(dev)
 
 
 def broadcast_seed(seed: Optional[int], device, src: int = 0) -> int:
@@ -88,7 +107,7 @@ def broadcast_seed(seed: Optional[int], device, src: int = 0) -> int:
     if not active():
         return int(seed)
     t = torch.tensor([int(seed)], dtype=torch.int64, device=device)
-    dist.broadcast(t, src=src)
+    _broadcast(t, src)
     return int(t.item())
 
 
@@ -114,7 +133,7 @@ def shard_generation_inputs(n_images: int, latent_shape, seed: Optional[int], de
         txt, vec = txt.to(device=device, dtype=dtype).contiguous(), vec.to(device=device, dtype=dtype).contiguous()
         meta = torch.tensor([*txt.shape, *vec.shape], dtype=torch.int64, device=device)
     if active():
-        dist.broadcast(meta, src=src)
+        _broadcast(meta, src)
     m = [int(v) for v in meta.tolist()]
     txt, vec = broadcast_conditioning(txt, vec, shapes=(tuple(m[:3]), tuple(m[3:])), src=src, device=device, dtype=dtype)
     if txt.shape[0] == 1:
@@ -141,7 +160,7 @@ def broadcast_tensors(tensors, src: int = 0, bucket_bytes: int = 1 << 28) -> int
         if not small:
             return
         flat = torch.cat([t.reshape(-1).view(torch.uint8) for t in small])
-        dist.broadcast(flat, src=src)
+        _broadcast(flat, src)
         if rank != src:
             off = 0
             for t in small:
@@ -157,7 +176,7 @@ def broadcast_tensors(tensors, src: int = 0, bucket_bytes: int = 1 << 28) -> int
         n = t.numel() * t.element_size()
         total += n
         if n >= (1 << 22):
-            dist.broadcast(t.view(-1).view(torch.uint8), src=src)     # raw bytes: bf16 is not supported by every gloo build
+            _broadcast(t.view(-1).view(torch.uint8), src)     # raw bytes: bf16 is not supported by every gloo build
         else:
             small.append(t)
             pending += n
@@ -189,7 +208,7 @@ def broadcast_from(make, device, src: int = 0):
         for t in ts:
             h += [_DTYPES.index(t.dtype), t.dim()] + list(t.shape) + [0] * (MAXD - t.dim())
         hdr[: len(h)] = torch.tensor(h, dtype=torch.int64)
-    dist.broadcast(hdr, src=src)
+    _broadcast(hdr, src)
     h = [int(v) for v in hdr.tolist()]
     if rank != src:
         ts = []
@@ -198,7 +217,7 @@ def broadcast_from(make, device, src: int = 0):
             ts.append(torch.empty(h[o + 2: o + 2 + h[o + 1]], dtype=_DTYPES[h[o]], device=device))
     for t in ts:
         if t.numel():
-            dist.broadcast(t.view(-1).view(torch.uint8), src=src)
+            _broadcast(t.view(-1).view(torch.uint8), src)
     return ts
 
 

@@ -554,3 +554,27 @@ def test_weight_broadcast_nccl_world1(dev, monkeypatch):
         assert torch.equal(got, want)
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_end_to_end(dev, tmp_path):
+    """The N > 1 path on real kernels: TWO processes (ranks 0 and 1 of one job) share this GPU — gloo carries the collectives,
+    since RCCL refuses two ranks on one device; everything else is production: rank 0 alone builds and runs T5 / CLIP and
+    broadcasts txt / vec, both ranks draw the full 5-image prior from the job seed and keep 3 / 2 rows, denoise and decode
+    with libfluxhip, and rank 0 gathers the uint8 images — which must equal the single-process run of the same seed, bit
+    for bit (tests/dist_gpu_worker.py)."""
+    import socket
+    import subprocess
+    import sys
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gpu_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(tmp_path / f"r{r}.pt")], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    res = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
+    assert res[0]["ok"] and res[1]["ok"], res
+    assert res[0]["shard"] == (0, 3) and res[1]["shard"] == (3, 5)
