@@ -305,7 +305,7 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
       return FLUXHIP_EINVAL;                        // no (or too small a) split-K workspace
     p.sk_flag = (int*)g_ws;
     p.sk_part = (float*)(g_ws + kSkFlagBytes);
-    p.sk_mode = (!p.addvec && rs_ok(cfg_idx, splits, tiles, conv, x3, f8)) ? 1 : 0;
+    p.sk_mode = (wide && !p.addvec && rs_ok(cfg_idx, splits, tiles, conv, x3, f8)) ? 1 : 0;   // (the direct-store epilogue is not ownership-aware)
     p.sk_depart = p.sk_flag + kSkMaxTiles / 2;
     g_rs_launches += p.sk_mode != 0;
   }

@@ -987,7 +987,13 @@ void gemm_nt_kernel(const GemmParams p) {
       int* arrive = p.sk_flag + bid;
       if (tid == 0) {
         __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(1);
+        // bounded spin: the peers are resident by construction (grid <= CUs); if that ever fails to hold — CUs masked away from
+        // this process, a device partition mode — the launch dies loudly (trap) after ~1 s instead of hanging the queue
+        unsigned spins = 0;
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 24)) __builtin_trap();
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv: this CU's L1 may hold last launch's slab lines
       }
       __syncthreads();

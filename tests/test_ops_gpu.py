@@ -156,6 +156,19 @@ def test_gemm_split_k_reduce_scatter(dev, cfg, S):
     assert torch.equal(again, outs[0])
 
 
+def test_gemm_split_k_narrow_rows_stay_on_the_chain(dev):
+    """Outputs that are only 8-byte addressable per row (N = 260) take the direct-store epilogue, which writes every fragment a
+    block holds: such launches must NOT use the reduce-scatter hand-off (a block would store the partial sums of fragments it
+    does not own).  They fall back to the chain and stay correct."""
+    from flux_generator_amd import ops
+    M, N, K = 600, 260, 1024
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    n0 = _rs_launches()
+    y = ops.linear(x, w, b, tile_cfg=51 | (3 << 8))
+    assert _rs_launches() == n0
+    assert rel_l2(y, O.linear(x.float().cpu(), w.float().cpu(), b.float().cpu())) < TOL
+
+
 def test_gemm_split_k_reduce_scatter_under_uneven_load(dev):
     """The S blocks of a tile wait for EACH OTHER: run the Flux shapes (linear2: 1280 x 3072 x 15360, S = 3, 240 blocks) while a
     second stream keeps taking CUs and memory bandwidth away (blocks of one tile then start far apart), alternating two
