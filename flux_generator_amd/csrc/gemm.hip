@@ -197,8 +197,6 @@ int g_num_cus = 0;                                    // CUs of the bound device
 // FLUXHIP_SPLITK=chain (or fluxhip_gemm_set_splitk_mode(1)) keeps every split-K launch on the chain (A/B runs, diagnostics)
 bool g_rs_enabled = [] { const char* e = getenv("FLUXHIP_SPLITK"); return !(e && e[0] == 'c'); }();
 long long g_rs_launches = 0;
-// FLUXHIP_PERSIST=0 keeps multi-round grids on one workgroup per tile (A/B runs)
-bool g_persist_enabled = [] { const char* e = getenv("FLUXHIP_PERSIST"); return !(e && e[0] == '0'); }();
 
 // Can a split-K launch of `cfg` with S splits over `tiles` output tiles use the reduce-scatter hand-off?
 bool rs_ok(int cfg, int S, long long tiles, bool conv, bool x3, bool f8) {
@@ -311,22 +309,7 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     p.sk_depart = p.sk_flag + kSkMaxTiles / 2;
     g_rs_launches += p.sk_mode != 0;
   }
-  long long nblocks = (long long)tm_total * p.tiles_n * splits;
-  // multi-round grids of the ping-pong dense tiles: one persistent workgroup per CU walks the tiles (gemm_core.h)
-  p.persist = 0;
-  if (g_persist_enabled && !conv && !x3 && splits == 1 && cfg_idx >= 49 && cfg_idx <= 55) {
-    if (g_num_cus == 0) {
-      int dev = 0;
-      hipDeviceProp_t pr;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) g_num_cus = pr.multiProcessorCount;
-    }
-    const int cus = g_num_cus & ~7;
-    if (cus >= 8 && nblocks > cus && nblocks < (1ll << 30)) {
-      p.persist = (int)nblocks;
-      nblocks = cus;
-    }
-  }
-  dim3 grid((unsigned)nblocks), block(c.threads);
+  dim3 grid(tm_total * p.tiles_n * splits), block(c.threads);
   hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }

@@ -96,7 +96,6 @@ struct GemmParams {
   int sk_mode;           // 0: chain (block s adds the partial of block s-1);  1: reduce-scatter (ping-pong tiles only, every
                          //    split block resident at once: grid <= CUs) — see the split-K note at the hand-off
   int* sk_depart;        // sk_mode 1: [tiles] departure counters (zero between launches; the last block to leave resets both)
-  int persist;           // > 0: number of virtual blocks (output tiles) a gridDim-sized set of persistent workgroups walks
   int wide_epi;          // outputs / residual / gate are 16-byte addressable: LDS-transposed epilogue
   unsigned long long* trace;  // FLAG_TIMED kernels only: [nblk][nwaves][8] summed segment cycles
   // FLAG_SPLIT kernels only ("bf16x3": fp32-faithful products on the bf16 matrix cores).  Every operand is a pair
@@ -183,17 +182,8 @@ void gemm_nt_kernel(const GemmParams p) {
   // and either hands the sum on (s < S-1) or runs the epilogue (s = S-1): a fixed summation order, so the
   // result is deterministic.  Block s only ever waits for a block with a LOWER block id, which the
   // dispatcher has already started, so the chain cannot deadlock even when the grid exceeds the chip.
-  // Persistent tile loop (p.persist: ping-pong dense tiles on multi-round grids — more output tiles than CUs).  A round-based
-  // grid pays a tile's whole fixed cost per round: block teardown, dispatch of the next block, its address setup, the
-  // chip-wide prologue fill, and the store burst of the epilogue with nothing behind it (linear1 at batch 1: 2 x 78 us for
-  // 2 x 240 tiles).  Here one workgroup per CU walks the tiles vb, vb + gridDim, ...: the global stores of tile t's epilogue
-  // drain while tile t + 1 computes its addresses and fills its ring (stores are fire-and-forget; the only ordering a new
-  // tile needs is that every wave has finished READING the LDS staging of the old one: the barrier at the loop's end).
-  // gridDim is a multiple of 8, so a workgroup's tiles keep its XCD's slice of the block -> tile map.
-  const int nvblk = p.persist ? p.persist : (int)gridDim.x;
-  for (int vblk = blockIdx.x; vblk < nvblk; vblk += gridDim.x) {
   const int S = p.splits;
-  int nblk = nvblk, bid = vblk, sidx = 0;
+  int nblk = gridDim.x, bid = blockIdx.x, sidx = 0;
   // Reduce-scatter split-K (sk_mode 1, see the hand-off after the main loop) exchanges its partials through memory, so the
   // S blocks of a tile need not share an XCD — and should not: with K = 12288 / 15360 the main loop of the N = 3072
   // projections is FABRIC-bound (phase trace: 1.0 us per K-step against 0.8 us of MFMA issue), because under the tile-major
@@ -1362,11 +1352,6 @@ void gemm_nt_kernel(const GemmParams p) {
       t[12] = t_epiA - t_loop1;      // epilogue phase A (barrier, bias, LDS writes)
       t[13] = t_epiB - t_epiA;       // epilogue phase B issue (LDS reads, fused math, store issue)
       t[14] = t_epi0 - t_loop1;      // barrier after the main loop (wave skew)
-    }
-  }
-    if (vblk + (int)gridDim.x < nvblk) {             // persistent: the LDS staging / ring is free for the next tile
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
     }
   }
 }
