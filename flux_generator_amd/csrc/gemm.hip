@@ -28,6 +28,7 @@ struct TileCfg {
   void (*conv_x3)(const GemmParams);
   void (*dense_f8)(const GemmParams);   // FLAG_FP8 (e4m3 x e4m3 on the 16x16x128 block-scaled MFMA); simple-ring and ping-pong tiles
   int wm = 1;                           // waves along M (rows per wave = bm / wm)
+  void (*dense_rs)(const GemmParams) = nullptr;   // FLAG_RS (split-K reduce-scatter hand-off) variant: 256 x 256 / 256 x 192 ping-pong
 };
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE, int FLAGS = 0>
@@ -54,6 +55,12 @@ template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
 constexpr TileCfg make_cfg_x3_f8() {
   TileCfg c = make_cfg_x3<BM, BN, WM, WN, NSTAGE, PIPE>();
   c.dense_f8 = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_FP8>;
+  return c;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE, int EXTRA = 0>
+constexpr TileCfg with_rs(TileCfg c) {
+  c.dense_rs = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_RS | EXTRA>;
   return c;
 }
 
@@ -108,18 +115,18 @@ const TileCfg kCfgs[] = {
     make_cfg<256, 128, 4, 2, 3, 5>(),     // 46: cfg 41 "
     make_cfg_x3<128, 128, 2, 4, 3, 5>(),     // 47: cfg 40 "
     make_cfg<256, 256, 4, 2, 2, 5, 1>(),  // 48: cfg 43 with phase stamps (diagnostic: fluxhip_gemm_set_trace, tools/gemm_phase_trace.py)
-    make_cfg_x3_f8<256, 256, 4, 2, 2, 6>(),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
+    with_rs<256, 256, 4, 2, 2, 6>(make_cfg_x3_f8<256, 256, 4, 2, 2, 6>()),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
     make_cfg_f8<256, 224, 4, 2, 2, 6>(),     // 50: cfg 44 "
-    make_cfg_f8<256, 192, 4, 2, 2, 6>(),     // 51: cfg 45 "
+    with_rs<256, 192, 4, 2, 2, 6>(make_cfg_f8<256, 192, 4, 2, 2, 6>()),     // 51: cfg 45 "
     make_cfg_f8<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
     make_cfg_f8<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
     make_cfg_f8<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
     make_cfg_x3_f8<128, 256, 2, 4, 2, 6>(),     // 55: 128x256, ping-pong
-    make_cfg<256, 192, 4, 2, 2, 6, 1>(),        // 56: cfg 51 with stamps around the main loop, the split-K reduce-scatter segments and the epilogue (diagnostic)
+    with_rs<256, 192, 4, 2, 2, 6, 1>(make_cfg<256, 192, 4, 2, 2, 6, 1>()),        // 56: cfg 51 with stamps around the main loop, the split-K reduce-scatter segments and the epilogue (diagnostic)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-bool g_attr_set[kNumCfgs][5] = {};
+bool g_attr_set[kNumCfgs][6] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
 // Tile choice: time model fitted to tools/gemm_tune.py sweeps (profiles/r01_gemm_tune_*.txt):
@@ -200,8 +207,9 @@ long long g_rs_launches = 0;
 
 // Can a split-K launch of `cfg` with S splits over `tiles` output tiles use the reduce-scatter hand-off?
 bool rs_ok(int cfg, int S, long long tiles, bool conv, bool x3, bool f8) {
-  if (!g_rs_enabled || conv || x3 || f8 || cfg < 49 || cfg > 56 || S < 2) return false;
+  if (!g_rs_enabled || conv || x3 || f8 || cfg <= 0 || cfg >= kNumCfgs || S < 2) return false;
   const TileCfg& t = kCfgs[cfg];
+  if (!t.dense_rs) return false;
   const int mi = t.bm / t.wm / 16, nj = t.bn / (t.threads / 64 / t.wm) / 16;
   if (mi % S && nj % S) return false;
   if (g_num_cus == 0) {
@@ -308,6 +316,13 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     p.sk_mode = (wide && !p.addvec && rs_ok(cfg_idx, splits, tiles, conv, x3, f8)) ? 1 : 0;   // (the direct-store epilogue is not ownership-aware)
     p.sk_depart = p.sk_flag + kSkMaxTiles / 2;
     g_rs_launches += p.sk_mode != 0;
+    if (p.sk_mode) {
+      fn = c.dense_rs;
+      if (!g_attr_set[cfg_idx][5]) {
+        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess) return FLUXHIP_ELAUNCH;
+        g_attr_set[cfg_idx][5] = true;
+      }
+    }
   }
   dim3 grid(tm_total * p.tiles_n * splits), block(c.threads);
   hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);

@@ -135,6 +135,11 @@ enum GemmFlags : int {
   // consecutive K bytes are the two 16-byte chunks 2q and 2q+1 of its row (bf16: chunk q for MFMA 0, 4+q for MFMA 1),
   // and the pair feeds ONE 16x16x128 MFMA where the bf16 loop issues two 16x16x32.  Same cycles per K-step, 2x K.
   FLAG_FP8 = 4,
+  // split-K reduce-scatter hand-off (see the hand-off after the main loop): its own instantiations.  The ownership-aware
+  // epilogue (runtime trip counts, owned-fragment tests) and the brick block map cost the launches that do NOT split 2 % when
+  // they share the kernel (build-to-build A/B, tools/lib_ab.py: mlp0 87.1 -> 88.7 us, linear1 150.0 -> 153.0 us), so only the
+  // tiles the picker splits (256 x 192, 256 x 256) carry a second kernel with it.
+  FLAG_RS = 16,
 };
 
 template <int N>
@@ -192,7 +197,7 @@ void gemm_nt_kernel(const GemmParams p) {
   // (split-major, N-tile, M-tile) order — 240 blocks: every XCD owns ONE K range, 6 N-tiles and all 5 M-tiles — so an XCD
   // reads a third of the activation panel (once per brick row) and its own weight panels: ~215 MB per launch.
   bool rs_map = false;
-  if constexpr (PIPE == 6 && (FLAGS & (FLAG_SPLIT | FLAG_FP8)) == 0 && AMODE == 0) rs_map = S > 1 && p.sk_mode != 0;
+  if constexpr ((FLAGS & FLAG_RS) != 0) rs_map = S > 1 && p.sk_mode != 0;
   int swz;
   if (rs_map) {
     const int T = nblk / S;
@@ -955,7 +960,8 @@ void gemm_nt_kernel(const GemmParams p) {
   // them only.  All S hand-offs are concurrent; bytes per block: (S-1)/S of a tile out, the same in.  Placement
   // independent (cdna guide, Guideline 16 R1); the blocks wait for EACH OTHER, so the launcher only selects this mode when
   // the whole grid is resident (one block per CU, grid <= CUs).  The last block to leave a tile zeroes both counters.
-  constexpr bool RS_CAPABLE = PP && !X3 && !F8 && AMODE == 0;
+  constexpr bool RS_CAPABLE = (FLAGS & FLAG_RS) != 0;
+  static_assert(!RS_CAPABLE || (PP && !X3 && !F8 && AMODE == 0), "reduce-scatter split-K: ping-pong dense bf16 tiles");
   bool rs = false;
   if constexpr (RS_CAPABLE) {
     if (S > 1 && p.sk_mode != 0) {

@@ -123,10 +123,10 @@ def _rs_launches():
     return int(_lib.load().fluxhip_gemm_rs_launches())
 
 
-@pytest.mark.parametrize("cfg,S", [(49, 2), (49, 4), (50, 2), (50, 4), (51, 2), (51, 3), (51, 4), (52, 2), (52, 4), (53, 2), (53, 4),
-                                   (54, 2), (54, 4), (55, 2), (55, 4)])
+@pytest.mark.parametrize("cfg,S", [(49, 2), (49, 4), (51, 2), (51, 3), (51, 4), (56, 3)])
 def test_gemm_split_k_reduce_scatter(dev, cfg, S):
-    """The reduce-scatter split-K hand-off (ping-pong tiles, whole grid resident): every supported (tile, S) — ownership by
+    """The reduce-scatter split-K hand-off (the tiles that carry a FLAG_RS kernel: 256 x 256, 256 x 192 and its phase-stamped
+    twin; whole grid resident): every supported (tile, S) — ownership by
     fragment rows (MI % S == 0) or by fragment columns (256 x 192 with S = 3) — with ragged M / N edges and the fused
     epilogues that the Flux plan runs through it; the launch must really take the reduce-scatter path, agree with the chain
     hand-off up to fp32 summation order, be repeatable bit for bit and leave the counters clean."""
@@ -154,6 +154,18 @@ def test_gemm_split_k_reduce_scatter(dev, cfg, S):
     assert rel_l2(outs[0], chain.float().cpu()) < 4e-3
     again = ops.linear(x, w, b, epi=ops.EPI_GATE_RES, res=res, gate=gate, tile_cfg=code)      # counters were left clean
     assert torch.equal(again, outs[0])
+
+
+def test_gemm_split_k_tiles_without_rs_kernel_use_the_chain(dev):
+    """Tiles without a FLAG_RS instantiation (e.g. 256 x 224, 128 x 256 ping-pong) split through the chain hand-off."""
+    from flux_generator_amd import ops
+    M, N, K = 600, 520, 1024
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = O.linear(x.float().cpu(), w.float().cpu(), b.float().cpu())
+    for cfg, S in ((50, 2), (55, 2), (52, 4)):
+        n0 = _rs_launches()
+        y = ops.linear(x, w, b, tile_cfg=cfg | (S << 8))
+        assert _rs_launches() == n0 and rel_l2(y, ref) < TOL
 
 
 def test_gemm_split_k_narrow_rows_stay_on_the_chain(dev):
