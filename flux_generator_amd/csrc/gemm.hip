@@ -129,25 +129,34 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 bool g_attr_set[kNumCfgs][6] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
-// Tile choice: time model fitted to tools/gemm_tune.py sweeps (profiles/r01_gemm_tune_*.txt):
-//   time = ceil(tiles / (256 CUs x blocks/CU)) x (K/64 x t_step + t_fixed)
-// t_step = one K-step of the main loop, t_fixed = prologue fill + epilogue + launch tail of one tile round
-// (tools/fit_tiles.py).  With cold (HBM-streamed) weights the fit is within 4-8 % for the one-block-per-CU tiles.
-struct Cand { int cfg; int bpc; float t_step_us; float t_fixed_us; };
+// Tile choice: a time model per tile, fitted to tools/gemm_tune.py sweeps.
+//   time = t_launch + R(x) * g(x) * (K/64 * t_step + t_fixed),   x = tiles / (256 CUs x blocks/CU)
+// t_step = one K-step of the main loop with every CU busy, t_fixed = prologue fill + epilogue of one tile round
+// (tools/fit_tiles.py).  Round 3 refit of the dense bf16 table on 111 shapes (Flux at 512^2 / 1024^2 / batch 4, T5, CLIP and
+// the SD / SDXL transformer GEMMs at batch 1..16), each timed from a replayed hipGraph (profiles/r03_gemm_tune_*.txt):
+//   g(x) = phi + (1 - phi) min(1, x): a round that leaves CUs idle runs faster (clocks, L2 / fabric contention) - phi = 0.6-0.7
+//          for every one-block-per-CU tile, which the round-1/2 model (g = 1) did not have: it over-priced the large tiles on
+//          the under-filled SDXL launches (M = 4096, N = 1280: picked 128x128 x 2 blocks/CU at 35 us, 128x256 takes 25.7 us);
+//   R(x) = 1 for x <= 1, else (1 - beta) x + beta ceil(x): the last partial round costs less than a whole one.
+// Mean regret (time of the pick / time of the best candidate) over the 111 shapes 1.069 -> 1.005, worst 1.45 -> 1.15; the
+// in-situ choices of the Flux plans (256x192 split-K 3 for mlp2 / linear2, 256x224 for linear1, ...) are unchanged.
+// The conv / fp32-faithful / fp8 tables below keep the round-1/2 form (phi = 1, beta = 1, t_launch = 0).
+struct Cand { int cfg; int bpc; float t_step_us; float t_fixed_us; float phi = 1.0f; };
+struct CostForm { float t_launch_us, beta; };
+constexpr CostForm kPlainForm = {0.0f, 1.0f}, kDenseForm = {1.79f, 0.46f};
 const Cand kCands[] = {
-    {49, 1, 1.072f, 22.1f},   // 256x256, ping-pong schedule, 2 + 3 ring
-    {50, 1, 1.010f, 18.7f},   // 256x224  "
-    {51, 1, 0.875f, 17.0f},   // 256x192  "
-    {54, 1, 0.819f, 14.3f},   // 256x160  "
-    {46, 1, 0.748f, 12.1f},   // 256x128, spread LDS-DMA + fragment reads, 3 + 4 ring
-    {55, 1, 0.787f, 10.9f},   // 128x256, ping-pong
-    {47, 1, 0.564f, 5.71f},   // 128x128, 8 waves, spread reads
-    // two blocks per CU: refitted in round 2 on the SDXL UNet shapes (M = 16384 / 4096, K = 640 .. 5120, many rounds), where the
-    // round-1 constants made the picker prefer 128x64 over 256x160 for the 16384 x 1280 x 640 q/k projection (411 vs 632 TFLOP/s)
-    {7, 2, 1.010f, 5.5f},     // 128x128, 4 waves, 2 blocks/CU
-    {8, 2, 0.920f, 3.8f},     // 128x64
-    {9, 2, 0.672f, 2.90f},    // 64x128 (round-1 fit kept: with cold K = 3072 weights it must stay behind the 128x128 8-wave tile)
-    {4, 2, 0.637f, 0.15f},    // 64x64
+    {49, 1, 1.590f, 9.17f, 0.56f},    // 256x256, ping-pong schedule, 2 + 3 ring
+    {50, 1, 1.424f, 10.63f, 0.67f},   // 256x224  "
+    {51, 1, 1.197f, 9.51f, 0.64f},    // 256x192  "
+    {54, 1, 1.223f, 8.38f, 0.62f},    // 256x160  "
+    {46, 1, 1.023f, 7.18f, 0.62f},    // 256x128, spread LDS-DMA + fragment reads, 3 + 4 ring
+    {55, 1, 0.990f, 5.06f, 0.68f},    // 128x256, ping-pong
+    {47, 1, 0.606f, 3.69f, 0.69f},    // 128x128, 8 waves, spread reads
+    // two blocks per CU (per-step time with both blocks resident)
+    {7, 2, 1.244f, 5.95f, 0.63f},     // 128x128, 4 waves
+    {8, 2, 0.938f, 2.34f, 0.58f},     // 128x64
+    {9, 2, 0.737f, 2.34f, 0.78f},     // 64x128
+    {4, 2, 0.546f, 1.06f, 0.92f},     // 64x64
 };
 
 // The implicit-GEMM (conv) loader has its own table (tools/conv_tune.py): its K-step carries the tap /
@@ -199,7 +208,7 @@ constexpr long long kSkFlagBytes = (long long)kSkMaxTiles * 4;
 char* g_ws = nullptr;
 long long g_ws_bytes = 0;
 constexpr float kHopUs = 20.0f, kHopNextUs = 8.0f;   // measured cost of the first / each further hand-off of a chain
-constexpr float kRsHopUs = 9.0f, kRsHopNextUs = 1.0f; // reduce-scatter hand-off (all S exchanges concurrent)
+constexpr float kRsHopUs = 9.0f, kRsHopNextUs = 4.0f; // reduce-scatter hand-off (all S exchanges concurrent)
 int g_num_cus = 0;                                    // CUs of the bound device (reduce-scatter needs the whole grid resident)
 // FLUXHIP_SPLITK=chain (or fluxhip_gemm_set_splitk_mode(1)) keeps every split-K launch on the chain (A/B runs, diagnostics)
 bool g_rs_enabled = [] { const char* e = getenv("FLUXHIP_SPLITK"); return !(e && e[0] == 'c'); }();
@@ -224,7 +233,8 @@ bool rs_ok(int cfg, int S, long long tiles, bool conv, bool x3, bool f8) {
 
 // returns cfg | (splits << 8)
 template <int NC, bool RS = false>
-int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbatch, int N, int K) {
+int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbatch, int N, int K,
+              const CostForm& form = kPlainForm) {
   float best = 3.4e38f;
   int best_cfg = 4;
   const int nkt = K / 64;
@@ -239,11 +249,15 @@ int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbat
         if (c.bpc != 1 || tiles * S > slots || nkt / S < 16 || tiles > kSkMaxTiles) break;
         if (kSkFlagBytes + tiles * t.bm * t.bn * 4LL > g_ws_bytes) break;
       }
-      const long long rounds = (tiles * S + slots - 1) / slots;
+      const float x = (float)(tiles * S) / (float)slots;
+      const float whole = (float)((tiles * S + slots - 1) / slots);
+      const float rounds = x <= 1.f ? 1.f : (1.f - form.beta) * x + form.beta * whole;
+      const float fill = c.phi + (1.f - c.phi) * (x < 1.f ? x : 1.f);
       const float hop = S == 1 ? 0.f
                         : (RS && rs_ok(c.cfg, S, tiles, false, false, false)) ? kRsHopUs + (float)(S - 2) * kRsHopNextUs
                                                                              : kHopUs + (float)(S - 2) * kHopNextUs;
-      const float cost = (float)rounds * ((float)((nkt + S - 1) / S) * c.t_step_us + c.t_fixed_us) + hop;
+      const float cost =
+          form.t_launch_us + rounds * fill * ((float)((nkt + S - 1) / S) * c.t_step_us + c.t_fixed_us) + hop;
       if (cost < best) { best = cost; best_cfg = c.cfg | (S << 8); }
     }
   }
@@ -257,7 +271,7 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
     return conv ? pick_from(kX3ConvCands, group_m, ngroups, nbatch, N, 3 * K)
                 : pick_from(kX3Cands, group_m, ngroups, nbatch, N, 3 * K);
   return conv ? pick_from(kConvCands, group_m, ngroups, nbatch, N, K)
-              : pick_from<sizeof(kCands) / sizeof(kCands[0]), true>(kCands, group_m, ngroups, nbatch, N, K);
+              : pick_from<sizeof(kCands) / sizeof(kCands[0]), true>(kCands, group_m, ngroups, nbatch, N, K, kDenseForm);
 }
 
 int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false, bool f8 = false) {
