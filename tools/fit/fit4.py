@@ -1,7 +1,9 @@
 import numpy as np, sys, math
 from scipy.optimize import least_squares
 from model import *
-data=load(["sdxl_gemm_tune_graph.txt","flux_gemm_tune_graph.txt"])
+import os
+PROF=os.path.join(os.path.dirname(os.path.abspath(__file__)),"..","..","profiles")
+data=load([os.path.join(PROF,"r03_gemm_tune_sd_sdxl_graph.txt"),os.path.join(PROF,"r03_gemm_tune_flux_t5_graph.txt")])
 cfgs=[c for c in sorted(TILES) if c in CANDS]          # current candidates only
 BPC={c:(2 if c in (4,7,8,9) else 1) for c in cfgs}
 idx={c:i for i,c in enumerate(cfgs)}

@@ -1,7 +1,9 @@
 import numpy as np, math, sys, random
 import picks
 from model import *
-data=load(["sdxl_gemm_tune_graph.txt","flux_gemm_tune_graph.txt"])
+import os
+PROF=os.path.join(os.path.dirname(os.path.abspath(__file__)),"..","..","profiles")
+data=load([os.path.join(PROF,"r03_gemm_tune_sd_sdxl_graph.txt"),os.path.join(PROF,"r03_gemm_tune_flux_t5_graph.txt")])
 shapes=list(data.items())
 cfgs=picks.cfgs
 def evaluate(p):
