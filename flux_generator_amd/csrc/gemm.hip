@@ -159,17 +159,23 @@ const Cand kCands[] = {
     {4, 2, 0.546f, 1.06f, 0.92f},     // 64x64
 };
 
-// The implicit-GEMM (conv) loader has its own table (tools/conv_tune.py): its K-step carries the tap /
-// border address generation, so the plain 2-deep rings win there and the spread-DMA variants lose.
+// The implicit-GEMM (conv) loader has its own table: its K-step carries the tap / border address generation, so the
+// plain 2-deep rings win there and the spread-DMA variants lose.  Round 3: refitted in the dense table's form on the SD / SDXL
+// UNet conv shapes at batch 1, 2, 4 and 16 (tools/conv_tune_unet.py, profiles/r03_conv_tune_unet_b*.txt), and the 256x160 /
+// 256x192 / 256x224 ping-pong tiles joined the candidates: 320 = 2 x 160 and 640 = 4 x 160 output channels fill them exactly
+// (64x64x320 -> 320 at batch 16: 204 -> 159 us; 32x32x640 -> 640: 150 -> 127 us).
+constexpr CostForm kConvForm = {4.39f, 0.22f};
 const Cand kConvCands[] = {
-    {49, 1, 1.850f, 6.0f},    // 256x256, ping-pong (3-6 % over the plain ring, cfg 15, once its per-piece 64-bit bases stopped
-                              // being hoisted into scratch; the fused-upsample loader stays on cfg 15, see fluxhip_conv2d_*)
-    {10, 1, 1.110f, 4.8f},    // 256x128
-    {55, 1, 0.980f, 8.2f},    // 128x256, ping-pong (the address generation runs in the memory phase, off the MFMA wave)
-    {7, 2, 1.155f, 4.0f},     // 128x128, 2 blocks/CU
-    {8, 2, 0.847f, 0.30f},    // 128x64
-    {9, 2, 0.672f, 2.90f},    // 64x128
-    {4, 2, 0.483f, 1.15f},    // 64x64
+    {49, 1, 1.657f, 7.58f, 0.75f},    // 256x256, ping-pong (the fused-upsample loader stays on the plain ring, cfg 15, see fluxhip_conv2d_*)
+    {50, 1, 1.516f, 8.58f, 0.78f},    // 256x224  "
+    {51, 1, 1.433f, 7.69f, 0.77f},    // 256x192  "
+    {54, 1, 1.352f, 6.92f, 0.77f},    // 256x160  "
+    {10, 1, 1.161f, 5.82f, 0.72f},    // 256x128
+    {55, 1, 1.114f, 2.80f, 0.75f},    // 128x256, ping-pong (the address generation runs in the memory phase, off the MFMA wave)
+    {7, 2, 1.370f, 5.04f, 0.59f},     // 128x128, 2 blocks/CU
+    {8, 2, 0.767f, 5.47f, 0.75f},     // 128x64
+    {9, 2, 0.797f, 1.93f, 0.76f},     // 64x128
+    {4, 2, 0.484f, 1.78f, 1.00f},     // 64x64
 };
 
 // fp32-faithful (FLAG_SPLIT) kernels exist for these tiles only; same time model with 3 x the K-steps.
@@ -270,7 +276,7 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
   if (x3)   // three passes over K
     return conv ? pick_from(kX3ConvCands, group_m, ngroups, nbatch, N, 3 * K)
                 : pick_from(kX3Cands, group_m, ngroups, nbatch, N, 3 * K);
-  return conv ? pick_from(kConvCands, group_m, ngroups, nbatch, N, K)
+  return conv ? pick_from(kConvCands, group_m, ngroups, nbatch, N, K, kConvForm)
               : pick_from<sizeof(kCands) / sizeof(kCands[0]), true>(kCands, group_m, ngroups, nbatch, N, K, kDenseForm);
 }
 
