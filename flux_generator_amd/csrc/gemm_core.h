@@ -411,8 +411,12 @@ void gemm_nt_kernel(const GemmParams p) {
   // ---- fragment read offsets (same XOR as the staging source swizzle) ---------
   const int r16 = lane & 15, q4 = lane >> 4;
   int foff[2];
-  foff[0] = r16 * 128 + (((F8 ? 2 * q4 : q4) ^ (lane & 7)) << 4);
-  foff[1] = r16 * 128 + (((F8 ? 2 * q4 + 1 : 4 + q4) ^ (lane & 7)) << 4);
+  // FLAG_FP8: the lane's 32-byte operand of the 16x16x128 MFMA is chunks q4 and 4 + q4 of its row as well - the same two
+  // reads as bf16 - not the contiguous pair 2 q4, 2 q4 + 1: the K order inside a step is free as long as both operands use
+  // the same one, and with chunk 2 q4 the ds_read_b128 lane group {0-3, 12-15, 20-27} put two lanes on every 16-byte slot
+  // (rocprofv3: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE in the fp8 kernels against 2 % in the bf16 ones).
+  foff[0] = r16 * 128 + ((q4 ^ (lane & 7)) << 4);
+  foff[1] = r16 * 128 + (((4 + q4) ^ (lane & 7)) << 4);
 
   f32x4 acc[MI][NJ];
 #pragma unroll
