@@ -83,6 +83,8 @@ SIGNATURES = {
     "fluxhip_groupnorm_silu_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_void_p, c_int64, c_void_p]),
     "fluxhip_attention_strided_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                                c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
+    "fluxhip_attention_strided_vt_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                                  c_void_p, c_int64, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
     "fluxhip_layernorm_affine_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p]),
     "fluxhip_concat_channels_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "fluxhip_axpbypcz_bf16": (c_int, [c_void_p] * 4 + [c_int64, c_float, c_float, c_float, c_void_p]),
@@ -141,11 +143,16 @@ def load() -> C.CDLL:
     except ImportError:       # pragma: no cover - the C ABI is usable without torch
         pass
     lib = C.CDLL(str(LIB_PATH))
+    # FLUXHIP_LIB_AB=1 (tools/lib_ab.py: timing an OLDER build of the library against the current one through the current
+    # Python host code) tolerates symbols that build does not have yet and its ABI version; never set it for product runs
+    ab = bool(os.environ.get("FLUXHIP_LIB_AB")) and "FLUXHIP_LIB" in os.environ
     for name, (res, args) in SIGNATURES.items():
+        if ab and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fluxhip_abi_version() != 4:
+    if lib.fluxhip_abi_version() != 5 and not ab:
         raise RuntimeError("libfluxhip ABI version mismatch")
     if lib.fluxhip_arch() != b"gfx950":
         raise RuntimeError("libfluxhip was not built for gfx950")

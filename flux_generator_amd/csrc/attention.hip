@@ -34,6 +34,7 @@ struct AttnParams {
   long long q_bs, q_hs, q_rs;   // element strides: batch, head, row
   long long k_bs, k_hs, k_rs;
   int ldo, H, Tq, Tk, Tkpad, nqb;
+  long long vt_bs;          // element stride between the V^T images of two batches (H * HD * Tkpad when dense)
   float scale_log2;
   float scale;              // MODE 1: logits = scale * q.k + bias
   const bf16_t* bias;       // MODE 1: additive bias [H][Tq][Tk] (T5 relative position bias)
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
 
   const bf16_t* Qh = p.Q + b * p.q_bs + h * p.q_hs;
   const bf16_t* Kh = p.K + b * p.k_bs + h * p.k_hs;
-  const bf16_t* Vh = p.Vt + (long long)bh * HD * Tkpad;
+  const bf16_t* Vh = p.Vt + b * p.vt_bs + (long long)h * HD * Tkpad;
 
   const int qw = wave % NW, kp = wave / NW;   // query group of this wave, KV-tile parity
   const int q0 = qb * (NW * 32) + qw * 32;
@@ -833,6 +834,7 @@ extern "C" int fluxhip_attention_d128_bf16(const void* Q, const void* K, const v
   p.q_hs = p.k_hs = (long long)T * 128;
   p.q_bs = p.k_bs = (long long)H * T * 128;
   p.ldo = ldo; p.H = H; p.Tq = T; p.Tk = T; p.Tkpad = Tpad;
+  p.vt_bs = (long long)H * 128 * Tpad;
   p.nqb = (T + 127) / 128;
   p.scale_log2 = scale * 1.4426950408889634f;
   // fewer workgroups than two per CU: split the KV tiles over a second wave set instead (see attn_kernel)
@@ -857,25 +859,36 @@ extern "C" int fluxhip_attention_set_variant(int v) {
   return FLUXHIP_OK;
 }
 
-extern "C" int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
-                                              const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
-                                              const void* Vt, void* O, int ldo, int B, int H,
-                                              int head_dim, int Tq, int Tk, int Tkpad, float scale,
-                                              void* stream) {
+extern "C" int fluxhip_attention_strided_vt_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                                 const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                                 const void* Vt, int64_t vt_bs, void* O, int ldo, int B, int H,
+                                                 int head_dim, int Tq, int Tk, int Tkpad, float scale,
+                                                 void* stream) {
   if (!Q || !K || !Vt || !O || B < 1 || H < 1 || Tq < 1 || Tk < 1 || Tkpad % 64 || Tkpad < Tk)
     return FLUXHIP_EINVAL;
   if ((head_dim != 64 && head_dim != 128) || ldo % 4 || q_rs % 8 || k_rs % 8 || q_hs % 8 || k_hs % 8 ||
-      q_bs % 8 || k_bs % 8)
+      q_bs % 8 || k_bs % 8 || vt_bs % 8 || vt_bs < (int64_t)H * head_dim * Tkpad)
     return FLUXHIP_EINVAL;
   AttnParams p{};
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
   p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
   p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
+  p.vt_bs = vt_bs;
   p.ldo = ldo; p.H = H; p.Tq = Tq; p.Tk = Tk; p.Tkpad = Tkpad;
   p.nqb = (Tq + 127) / 128;
   p.scale_log2 = scale * 1.4426950408889634f;
   return head_dim == 128 ? launch_attn<128, 0>(p, B, (hipStream_t)stream)
                          : launch_attn<64, 0>(p, B, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                              const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                              const void* Vt, void* O, int ldo, int B, int H,
+                                              int head_dim, int Tq, int Tk, int Tkpad, float scale,
+                                              void* stream) {
+  return fluxhip_attention_strided_vt_bf16(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, Vt,
+                                           (int64_t)H * head_dim * Tkpad, O, ldo, B, H, head_dim, Tq, Tk, Tkpad,
+                                           scale, stream);
 }
 
 extern "C" int fluxhip_attention_masked_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
@@ -893,6 +906,7 @@ extern "C" int fluxhip_attention_masked_bf16(const void* Q, int64_t q_bs, int64_
   p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
   p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
   p.ldo = ldo; p.H = H; p.Tq = Tq; p.Tk = Tk; p.Tkpad = Tkpad;
+  p.vt_bs = (long long)H * 64 * Tkpad;
   p.nqb = (Tq + 127) / 128;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.scale = scale;

@@ -5,8 +5,11 @@
 namespace {
 
 // nn.LayerNorm(dims) with affine weight/bias, eps 1e-5 (TransformerBlock.norm1/2/3,
-// stable_diffusion/.../unet.py:45,50,57). One wave per row, NCH 16-byte chunks per lane.
-template <int NCH>
+// stable_diffusion/.../unet.py:45,50,57).  WPR waves share a row (NCH 16-byte chunks per lane): at the UNet's widths a row
+// is 80 .. 160 chunks, so one wave per row left 3 dependent loads per lane and, at 4096 rows, 16 waves per CU to hide them
+// (10.5 us for 21 MB = 2 TB/s); two or four waves per row read it in one round and put 2-4 x the waves in flight.
+// The row statistics cross the waves through LDS in a fixed order (deterministic).
+template <int NCH, int WPR>
 __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __restrict__ x,
                                                                bf16_t* __restrict__ out,
                                                                long long rows, int D,
@@ -15,17 +18,40 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __r
                                                                float eps, int rms) {
   // rms != 0: nn.RMSNorm (x * rsqrt(mean(x^2) + eps) * gamma, no mean subtraction, no beta;
   // flux/t5.py:196-197,216)
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  __shared__ float red[2][4];
+  constexpr int LPR = 64 * WPR;                         // lanes per row
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & (LPR - 1);
+  long long row = (long long)blockIdx.x * (4 / WPR) + threadIdx.x / LPR;
+  const bool live = row < rows;                         // a dead row group walks the last row and stores nothing: every
+  if (!live) row = rows - 1;                            // wave reaches the block barriers below
   const bf16_t* xr = x + row * D;
   bf16_t* orow = out + row * D;
   const int nchunk = D >> 3;
+  auto group_sum = [&](float v, float* r) {
+    v = wave_sum(v);
+    if constexpr (WPR == 1) return v;
+    if ((threadIdx.x & 63) == 0) r[wave] = v;
+    __syncthreads();
+    const int w0 = wave & ~(WPR - 1);
+    float t = r[w0];
+#pragma unroll
+    for (int i = 1; i < WPR; ++i) t += r[w0 + i];
+    return t;
+  };
+  // gamma / beta do not depend on the statistics: request them with the row
+  u32x4 gw[NCH], bw[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = min(lane + i * LPR, nchunk - 1);
+    gw[i] = *((const u32x4*)gamma + c);
+    bw[i] = beta ? *((const u32x4*)beta + c) : u32x4{0, 0, 0, 0};
+  }
   float v[NCH][8];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    int c = lane + i * 64;
+    int c = lane + i * LPR;
     if (c < nchunk) {
       u32x4 w = *((const u32x4*)xr + c);
 #pragma unroll
@@ -40,11 +66,11 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __r
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += v[i][e];
   }
-  const float mean = rms ? 0.f : wave_sum(sum) / (float)D;
+  const float mean = rms ? 0.f : group_sum(sum, red[0]) / (float)D;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    int c = lane + i * 64;
+    int c = lane + i * LPR;
     if (c < nchunk) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -53,18 +79,17 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __r
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  const float rstd = rsqrtf(group_sum(sq, red[1]) / (float)D + eps);
+  if (!live) return;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    int c = lane + i * 64;
+    int c = lane + i * LPR;
     if (c < nchunk) {
-      u32x4 gw = *((const u32x4*)gamma + c);
-      u32x4 bw = beta ? *((const u32x4*)beta + c) : u32x4{0, 0, 0, 0};
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        o[e] = pack_bf16x2((v[i][2 * e] - mean) * rstd * bf_lo(gw[e]) + bf_lo(bw[e]),
-                           (v[i][2 * e + 1] - mean) * rstd * bf_hi(gw[e]) + bf_hi(bw[e]));
+        o[e] = pack_bf16x2((v[i][2 * e] - mean) * rstd * bf_lo(gw[i][e]) + bf_lo(bw[i][e]),
+                           (v[i][2 * e + 1] - mean) * rstd * bf_hi(gw[i][e]) + bf_hi(bw[i][e]));
       *((u32x4*)orow + c) = o;
     }
   }
@@ -174,18 +199,19 @@ __global__ __launch_bounds__(256) void embedding_kernel(const int* __restrict__ 
 static int run_layernorm(const void* x, void* out, int64_t rows, int D, const void* gamma, const void* beta,
                          float eps, int rms, void* stream) {
   if (!x || !out || !gamma || (!beta && !rms) || rows < 1 || D < 8 || D % 8 || D > 4096) return FLUXHIP_EINVAL;
-  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const int nch = (D + 511) / 512;
-#define LNA(NCH)                                                                                  \
-  hipLaunchKernelGGL((layernorm_affine_kernel<NCH>), grid, block, 0, s, (const bf16_t*)x,         \
+  const int nchunk = D / 8;
+  // waves per row: enough lanes that a row is read in one round up to D = 2048 (T5's 4096: two rounds of four waves)
+  const int wpr = nchunk > 128 ? 4 : nchunk > 64 ? 2 : 1;
+  const int nch = (nchunk + 64 * wpr - 1) / (64 * wpr);
+  dim3 grid((unsigned)((rows * wpr + 3) / 4)), block(256);
+#define LNA(NCH, WPR)                                                                             \
+  hipLaunchKernelGGL((layernorm_affine_kernel<NCH, WPR>), grid, block, 0, s, (const bf16_t*)x,    \
                      (bf16_t*)out, (long long)rows, D, (const bf16_t*)gamma, (const bf16_t*)beta, eps, rms)
-  if (nch <= 1) LNA(1);
-  else if (nch <= 2) LNA(2);
-  else if (nch <= 3) LNA(3);
-  else if (nch <= 4) LNA(4);
-  else if (nch <= 6) LNA(6);
-  else LNA(8);
+  if (wpr == 1) LNA(1, 1);
+  else if (wpr == 2) LNA(1, 2);
+  else if (nch <= 1) LNA(1, 4);
+  else LNA(2, 4);
 #undef LNA
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }

@@ -93,14 +93,18 @@ class StableDiffusion:
         return conditioning
 
     def _denoising_step(self, x_t, t, t_prev, conditioning, cfg_weight: float = 7.5, text_time=None, noise=None,
-                        key: Optional[torch.Generator] = None, coef_dev: Optional[torch.Tensor] = None, shard=None):
+                        key: Optional[torch.Generator] = None, coef_dev: Optional[torch.Tensor] = None, shard=None,
+                        new_conditioning: bool = True):
         """__init__.py:67-82.  One UNet step is ~1700 kernel launches; with use_graph they are captured ONCE per
         (shape, cfg) into a hipGraph over static input buffers: the timestep is a device tensor and the sampler's
         (ca, cb, cc) live in a float32[3] device buffer (fluxhip_axpbypcz_dev_bf16), so every step of every run
         replays the same graph.  The ancestral sampler's per-step noise is drawn from the run's seeded generator
         `key` outside the graph and copied into a static buffer.  coef_dev: this step's row of
         `sampler.coeff_table` (device float32[3]; `_denoising_loop` uploads the whole table once per run) — without it the
-        coefficients are computed and uploaded here.  shard: (lo, hi, n_total) of a multi-GPU run (noise rows)."""
+        coefficients are computed and uploaded here.  shard: (lo, hi, n_total) of a multi-GPU run (noise rows).
+        The cross-attention K / V^T of all transformer layers depend on the conditioning only: they live in static buffers
+        next to it (`UNetModel.text_kv`, two GEMMs per layer width) and are projected OUTSIDE the graph, when the
+        conditioning changes (new_conditioning: `_denoising_loop` passes False after the first step of a run)."""
         if noise is None and self.sampler.needs_noise:
             noise = self.sampler.draw_noise(x_t, key, shard)
         if not self.use_graph:
@@ -115,19 +119,23 @@ class StableDiffusion:
             sn = None if noise is None else noise.clone()
             st = torch.full((nb,), float(t), dtype=torch.float32, device=self.device)
             scoef = torch.tensor(self.sampler.coeffs(t, t_prev), dtype=torch.float32, device=self.device)
+            skv = self.unet.text_kv(self.unet.pad_encoder_states(sc))
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._denoising_step_dev(sx, st, scoef, sc, cfg_weight, stt, sn)      # warm-up
+                self._denoising_step_dev(sx, st, scoef, sc, cfg_weight, stt, sn, skv)      # warm-up
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self._denoising_step_dev(sx, st, scoef, sc, cfg_weight, stt, sn)
-            ent = (g, sx, sc, stt, sn, st, scoef, out)
+                out = self._denoising_step_dev(sx, st, scoef, sc, cfg_weight, stt, sn, skv)
+            ent = (g, sx, sc, stt, sn, st, scoef, out, skv)
             self._graph_put(key_, ent)
-        g, sx, sc, stt, sn, st, scoef, out = ent
+            new_conditioning = True
+        g, sx, sc, stt, sn, st, scoef, out, skv = ent
         sx.copy_(x_t)
-        sc.copy_(conditioning)
+        if new_conditioning:
+            sc.copy_(conditioning)
+            self.unet.text_kv(self.unet.pad_encoder_states(sc), out=skv)
         if stt is not None:
             stt[0].copy_(text_time[0])
             stt[1].copy_(text_time[1])
@@ -140,18 +148,18 @@ class StableDiffusion:
         g.replay()
         return out.clone()
 
-    def _eps(self, x_t, t_unet, conditioning, cfg_weight, text_time):
+    def _eps(self, x_t, t_unet, conditioning, cfg_weight, text_time, text_kv=None):
         """UNet evaluation with classifier-free guidance: CFG doubles the batch (text first, negative second)."""
         x_unet = torch.cat([x_t] * 2, dim=0) if cfg_weight > 1 else x_t
-        eps = self.unet(x_unet, t_unet, encoder_x=conditioning, text_time=text_time)
+        eps = self.unet(x_unet, t_unet, encoder_x=conditioning, text_time=text_time, text_kv=text_kv)
         if cfg_weight > 1:
             eps_text, eps_neg = eps.chunk(2)
             # eps_neg + w (eps_text - eps_neg) = (1 - w) eps_neg + w eps_text
             eps = ops.axpbypcz(eps_neg.contiguous(), eps_text.contiguous(), None, 1.0 - cfg_weight, cfg_weight)
         return eps
 
-    def _denoising_step_dev(self, x_t, t_unet, coef, conditioning, cfg_weight, text_time, noise):
-        return self.sampler.step_dev(self._eps(x_t, t_unet, conditioning, cfg_weight, text_time), x_t, coef, noise)
+    def _denoising_step_dev(self, x_t, t_unet, coef, conditioning, cfg_weight, text_time, noise, text_kv=None):
+        return self.sampler.step_dev(self._eps(x_t, t_unet, conditioning, cfg_weight, text_time, text_kv), x_t, coef, noise)
 
     def _denoising_step_eager(self, x_t, t, t_prev, conditioning, cfg_weight: float = 7.5, text_time=None, noise=None):
         nb = len(x_t) * (2 if cfg_weight > 1 else 1)
@@ -164,6 +172,7 @@ class StableDiffusion:
         x_t = x_T
         steps = self.sampler.timesteps(num_steps, start_time=T)
         coefs = self.sampler.coeff_table(steps, self.device) if self.use_graph else None
+        first = True                           # the conditioning (and its K / V^T projections) is new to the step graph once per run
         for i, (t, t_prev) in enumerate(steps):
             if len(x_t) == 0:          # more ranks than images: keep the job generator in step, nothing to compute
                 if self.sampler.needs_noise:
@@ -171,7 +180,8 @@ class StableDiffusion:
                 yield x_t
                 continue
             x_t = self._denoising_step(x_t, t, t_prev, conditioning, cfg_weight, text_time, key=key,
-                                       coef_dev=None if coefs is None else coefs[i], shard=shard)
+                                       coef_dev=None if coefs is None else coefs[i], shard=shard, new_conditioning=first)
+            first = False
             yield x_t
 
     # ------------------------------------------------------------------ multi-GPU front half

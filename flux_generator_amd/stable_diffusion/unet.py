@@ -185,6 +185,18 @@ class UNetModel:
             if k.endswith(".attn1.query_proj.weight"):
                 b = k[: -len(".query_proj.weight")]
                 F[f"{b}.qk"] = torch.cat([P[k], P[f"{b}.key_proj.weight"]], dim=0).contiguous()
+        # cross-attention: K and V^T depend on the text only -> all layers of one width are projected together
+        # (text_kv); group = (channels, encoder width), layer slot = row offset inside the concatenated weights
+        groups: Dict[Tuple[int, int], list] = {}
+        for k in P:
+            if k.endswith(".attn2.key_proj.weight"):
+                groups.setdefault(tuple(P[k].shape), []).append(k[: -len(".key_proj.weight")])
+        self._kv_slot: Dict[str, Tuple[Tuple[int, int], int]] = {}
+        for (C, enc), names in groups.items():
+            F[f"kv.{C}.{enc}.k"] = torch.cat([P[f"{n}.key_proj.weight"] for n in names], dim=0).contiguous()
+            F[f"kv.{C}.{enc}.v"] = torch.cat([P[f"{n}.value_proj.weight"] for n in names], dim=0).contiguous()
+            for i, n in enumerate(names):
+                self._kv_slot[n] = ((C, enc), i * C)
         w = P["conv_in.weight"]
         cin = w.shape[-1]
         if cin % 64:
@@ -208,41 +220,63 @@ class UNetModel:
             x = ops.conv2d(x, W[f"{p}.conv_shortcut.weight"], W[f"{p}.conv_shortcut.bias"])
         return ops.conv2d(h, W[f"{p}.conv2.weight"], W[f"{p}.conv2.bias"], res=x)
 
-    def _mha(self, p: str, H: int, y: torch.Tensor, n: torch.Tensor, mem: Optional[torch.Tensor], Tk: int) -> torch.Tensor:
+    def text_kv(self, mem: torch.Tensor, out: Optional[dict] = None) -> dict:
+        """key_proj / value_proj of the (zero-padded) encoder states `mem` [B,Tkp,enc] for EVERY cross-attention layer
+        (unet.py:46-54 applies them per layer; they depend on the text only): per (channels, enc) group one GEMM against
+        the concatenated key weights -> K [B,Tkp,sum C] and one batched GEMM V^T[b] = Wv_all mem[b]^T -> [B,sum C,Tkpad]
+        (padded keys stay zero).  A pipeline computes this once per job and passes it to every step (`text_kv=`);
+        `out` = a dict from an earlier call to overwrite in place (static buffers of a captured step graph)."""
+        B, Tkp, enc = mem.shape
+        Tkpad = (Tkp + 63) // 64 * 64
+        kv = out if out is not None else {"Tkp": Tkp, "Tkpad": Tkpad}
+        for key in {g for g, _ in self._kv_slot.values()}:
+            C, e = key
+            if e != enc:
+                raise ValueError(f"encoder width {enc} does not match the cross-attention projections ({e})")
+            Wk, Wv = self._fused[f"kv.{C}.{e}.k"], self._fused[f"kv.{C}.{e}.v"]
+            LC = Wk.shape[0]
+            if out is None:
+                kv[key] = (torch.empty(B, Tkp, LC, dtype=BF16, device=mem.device),
+                           torch.zeros(B, LC, Tkpad, dtype=BF16, device=mem.device))
+            k_all, vt_all = kv[key]
+            ops.linear(mem, Wk, out=k_all)
+            ops.gemm(make_gemm_desc([dict(A=Wv.data_ptr(), W=mem.data_ptr(), C=vt_all.data_ptr(), a_bstride=0,
+                                          w_bstride=Tkp * enc, c_bstride=LC * Tkpad, M=LC)], B, Tkp, enc, enc, Tkpad))
+        return kv
+
+    def _mha(self, p: str, H: int, y: torch.Tensor, n: torch.Tensor, kv: Optional[dict], Tk: int) -> torch.Tensor:
         """x + nn.MultiHeadAttention(n, kv, kv) (unet.py:46-54,64-71). y: residual [B,N,C]; n: normed
-        queries; mem: None for self-attention, else the zero-padded encoder states [B,Tkp,enc]."""
+        queries; kv: None for self-attention, else the projected encoder states of every layer (text_kv)."""
         W = self._params
         B, N, C = n.shape
         dev = n.device
-        if mem is None:
-            qk = ops.linear(n, self._fused[f"{p}.qk"])                       # [B,N,2C]
-            q_ptr, k_ptr = qk, qk[..., C:]                                     # views: strides below
-            q_str = (N * 2 * C, 64, 2 * C)
-            k_str = (N * 2 * C, 64, 2 * C)
-            kv_src, Tkp, kd = n, N, C
-        else:
-            q_ptr = ops.linear(n, W[f"{p}.query_proj.weight"])                # [B,N,C]
-            Tkp, kd = mem.shape[1], mem.shape[2]
-            k_ptr = ops.linear(mem, W[f"{p}.key_proj.weight"])                # [B,Tkp,C]
-            q_str = (N * C, 64, C)
-            k_str = (Tkp * C, 64, C)
-            kv_src = mem
-        Tkpad = (Tkp + 63) // 64 * 64
-        vt = torch.zeros(B, C, Tkpad, dtype=BF16, device=dev)
-        # V^T[b] = Wv kv[b]^T : A = Wv (shared), "W" operand = kv rows of batch b
-        ops.gemm(make_gemm_desc([dict(A=W[f"{p}.value_proj.weight"].data_ptr(), W=kv_src.data_ptr(), C=vt.data_ptr(),
-                                      a_bstride=0, w_bstride=Tkp * kd, c_bstride=C * Tkpad, M=C)],
-                                B, Tkp, kd, kd, Tkpad))
-        o = torch.empty(B, N, C, dtype=BF16, device=dev)
         lib = _lib.load()
-        rc = lib.fluxhip_attention_strided_bf16(q_ptr.data_ptr(), *q_str, k_ptr.data_ptr(), *k_str, vt.data_ptr(),
-                                                o.data_ptr(), C, B, H, 64, N, Tk, Tkpad, 64 ** -0.5,
-                                                torch.cuda.current_stream().cuda_stream)
+        o = torch.empty(B, N, C, dtype=BF16, device=dev)
+        if kv is None:
+            qk = ops.linear(n, self._fused[f"{p}.qk"])                       # [B,N,2C]
+            Tkpad = (N + 63) // 64 * 64
+            vt = torch.zeros(B, C, Tkpad, dtype=BF16, device=dev) if Tkpad != N else torch.empty(B, C, N, dtype=BF16, device=dev)
+            # V^T[b] = Wv n[b]^T : A = Wv (shared), "W" operand = the rows of batch b
+            ops.gemm(make_gemm_desc([dict(A=W[f"{p}.value_proj.weight"].data_ptr(), W=n.data_ptr(), C=vt.data_ptr(),
+                                          a_bstride=0, w_bstride=N * C, c_bstride=C * Tkpad, M=C)],
+                                    B, N, C, C, Tkpad))
+            rc = lib.fluxhip_attention_strided_bf16(qk.data_ptr(), N * 2 * C, 64, 2 * C, qk[..., C:].data_ptr(), N * 2 * C, 64, 2 * C,
+                                                    vt.data_ptr(), o.data_ptr(), C, B, H, 64, N, Tk, Tkpad, 64 ** -0.5,
+                                                    torch.cuda.current_stream().cuda_stream)
+        else:
+            q = ops.linear(n, W[f"{p}.query_proj.weight"])                    # [B,N,C]
+            key, off = self._kv_slot[p]
+            k_all, vt_all = kv[key]
+            LC, Tkp, Tkpad = k_all.shape[2], kv["Tkp"], kv["Tkpad"]
+            rc = lib.fluxhip_attention_strided_vt_bf16(q.data_ptr(), N * C, 64, C, k_all.data_ptr() + off * 2, Tkp * LC, 64, LC,
+                                                       vt_all.data_ptr() + off * Tkpad * 2, LC * Tkpad, o.data_ptr(), C,
+                                                       B, H, 64, N, Tk, Tkpad, 64 ** -0.5,
+                                                       torch.cuda.current_stream().cuda_stream)
         if rc:
-            raise FluxHipError(f"fluxhip_attention_strided_bf16 failed with code {rc}")
+            raise FluxHipError(f"fluxhip_attention_strided failed with code {rc}")
         return ops.linear(o, W[f"{p}.out_proj.weight"], W[f"{p}.out_proj.bias"], epi=EPI_GATE_RES, res=y)
 
-    def _transformer(self, p: str, H: int, layers: int, x: torch.Tensor, mem: torch.Tensor, Tk: int) -> torch.Tensor:
+    def _transformer(self, p: str, H: int, layers: int, x: torch.Tensor, mem: dict, Tk: int) -> torch.Tensor:
         """Transformer2D.__call__ (unet.py:108-124) with TransformerBlock (unet.py:61-81)."""
         W, G = self._params, self.config.norm_num_groups
         B, Hh, Ww, C = x.shape
@@ -283,8 +317,15 @@ class UNetModel:
         return x, outs
 
     # ------------------------------------------------------------------ forward
+    def pad_encoder_states(self, encoder_x: torch.Tensor) -> torch.Tensor:
+        """encoder states zero-padded to a multiple of 8 tokens (GEMM N granularity); padded keys are masked."""
+        B, S, e = encoder_x.shape
+        mem = torch.zeros(B, (S + 7) // 8 * 8, e, dtype=BF16, device=self.device)
+        mem[:, :S].copy_(encoder_x)
+        return mem
+
     def __call__(self, x: torch.Tensor, timestep: torch.Tensor, encoder_x: torch.Tensor, attn_mask=None,
-                 encoder_attn_mask=None, text_time=None) -> torch.Tensor:
+                 encoder_attn_mask=None, text_time=None, text_kv: Optional[dict] = None) -> torch.Tensor:
         """UNetModel.__call__ (unet.py:403-460). x [B,h,w,4] NHWC, timestep [B], encoder_x [B,S,enc]."""
         if attn_mask is not None or encoder_attn_mask is not None:
             raise NotImplementedError("masks are always None on the reference's path (unet.py:403-411)")
@@ -301,11 +342,9 @@ class UNetModel:
             h1 = small_linear_any(e, W["add_embedding.linear_1.weight"], W["add_embedding.linear_1.bias"])
             small_linear_any(h1, W["add_embedding.linear_2.weight"], W["add_embedding.linear_2.bias"], silu_in=True,
                              out=temb, accum=True)
-        # encoder states zero-padded to a multiple of 8 tokens (GEMM N granularity); padded keys are masked
+        # the cross-attention K / V^T of every layer: given by the caller (once per job) or projected here
         S = encoder_x.shape[1]
-        Sp = (S + 7) // 8 * 8
-        mem = torch.zeros(B, Sp, encoder_x.shape[2], dtype=BF16, device=self.device)
-        mem[:, :S].copy_(encoder_x)
+        mem = text_kv if text_kv is not None else self.text_kv(self.pad_encoder_states(encoder_x))
 
         cin = cfg.in_channels
         if cin % 64:

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define FLUXHIP_ABI_VERSION 4
+#define FLUXHIP_ABI_VERSION 5
 
 int fluxhip_abi_version(void);
 /* "gfx950" — the only architecture this library is built for. */
@@ -204,6 +204,15 @@ int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64_t q_hs, in
                                    const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
                                    const void* Vt, void* O, int ldo, int B, int H, int head_dim,
                                    int Tq, int Tk, int Tkpad, float scale, void* stream);
+
+/* The same with an explicit element stride vt_bs >= H*head_dim*Tkpad between the V^T images of two batches: the
+ * cross-attention K / V^T of every transformer layer of the UNet depend on the text only, so the host projects them for
+ * all layers in two launches (concatenated key_proj / value_proj weights) and each layer reads its [H*hd][Tkpad] slice of
+ * the [B][sum C][Tkpad] image (unet.py:46-54: the per-layer key_proj / value_proj of the encoder states). */
+int fluxhip_attention_strided_vt_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                      const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                      const void* Vt, int64_t vt_bs, void* O, int ldo, int B, int H,
+                                      int head_dim, int Tq, int Tk, int Tkpad, float scale, void* stream);
 
 /* nn.LayerNorm(D) with affine gamma/beta (unet.py:45,50,57), rows of width D <= 4096. */
 int fluxhip_layernorm_affine_bf16(const void* x, void* out, int64_t rows, int D, const void* gamma,

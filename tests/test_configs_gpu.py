@@ -241,7 +241,7 @@ def test_sdxl_full_width_transformer(dev, hw):
     ref = S.transformer_2d(W, "mid_blocks.1", 20, 2, x.float(), enc.float())
     mem = torch.zeros(B, 80, 2048, dtype=BF, device=dev)
     mem[:, :77] = enc.to(dev)
-    got = model._transformer("mid_blocks.1", 20, 2, x.to(dev), mem, 77)
+    got = model._transformer("mid_blocks.1", 20, 2, x.to(dev), model.text_kv(mem), 77)
     e = rel_l2(got, ref)
     print(f"sdxl transformer {hw}: rel-L2 {e:.2e}")
     assert got.shape == ref.shape and e < 1e-2

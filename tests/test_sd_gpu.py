@@ -36,6 +36,18 @@ def test_attention_d64(dev, B, H, Tq, Tk, cross):
     sp = lambda t, T: t.float().cpu().view(B, T, H, 64).transpose(1, 2)   # noqa: E731
     ref = O.sdpa(sp(q, Tq), sp(k, Tk), sp(v, Tk), 64 ** -0.5).transpose(1, 2).reshape(B, Tq, C)
     assert rel_l2(o, ref) < 6e-3
+    # the same V^T as a [C][Tkpad] slice of a wider per-batch image (explicit batch stride): the layout the UNet's
+    # all-layers text projection produces (UNetModel.text_kv); must be bit-identical to the dense call
+    from flux_generator_amd import _lib
+    wide = torch.randn(B, 3 * C, Tkpad, device=dev).to(BF)
+    wide[:, C:2 * C] = vt
+    o2 = torch.empty_like(o)
+    rc = _lib.load().fluxhip_attention_strided_vt_bf16(q.data_ptr(), Tq * C, 64, C, k.data_ptr(), Tk * C, 64, C,
+                                                       wide.data_ptr() + C * Tkpad * 2, 3 * C * Tkpad, o2.data_ptr(), C,
+                                                       B, H, 64, Tq, Tk, Tkpad, 64 ** -0.5, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and torch.equal(o, o2)
+    assert _lib.load().fluxhip_attention_strided_vt_bf16(q.data_ptr(), Tq * C, 64, C, k.data_ptr(), Tk * C, 64, C, wide.data_ptr(),
+                                                         C * Tkpad - 8, o2.data_ptr(), C, B, H, 64, Tq, Tk, Tkpad, 0.125, 0) != 0
 
 
 @pytest.mark.parametrize("C,hw", [(320, (16, 16)), (640, (8, 12)), (960, (8, 8)), (1920, (4, 4)), (128, (32, 32))])
@@ -115,6 +127,13 @@ def test_unet_forward_tiny(dev, xl):
     e = rel_l2(got, ref)
     print(f"unet tiny rel-L2 {e:.2e}")
     assert got.shape == ref.shape and e < 1.5e-2
+    # the text projections handed in by the caller (once per job) give the same bits as projecting inside the call
+    kv = model.text_kv(model.pad_encoder_states(enc.to(dev)))
+    got2 = model(x.to(dev), t.to(dev), enc.to(dev), text_time=None if tt is None else (tt[0].to(dev), tt[1].to(dev)), text_kv=kv)
+    assert torch.equal(got, got2)
+    kv2 = model.text_kv(model.pad_encoder_states(torch.zeros_like(enc).to(dev)))
+    model.text_kv(model.pad_encoder_states(enc.to(dev)), out=kv2)          # in-place refresh of existing buffers
+    assert all(torch.equal(a, b) for k_ in kv if isinstance(k_, tuple) for a, b in zip(kv[k_], kv2[k_]))
 
 
 def test_sd_denoising_step_cfg_and_samplers(dev):

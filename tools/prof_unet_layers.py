@@ -70,13 +70,14 @@ lib = _lib.load()
 _att = lib.fluxhip_attention_strided_bf16
 class LibProxy:
     def __getattr__(self, n):
-        if n != "fluxhip_attention_strided_bf16":
+        if n not in ("fluxhip_attention_strided_bf16", "fluxhip_attention_strided_vt_bf16"):
             return getattr(lib, n)
+        fn, sh = getattr(lib, n), int(n.endswith("_vt_bf16"))
         def f(*a):
-            # (q, qs0, qs1, qs2, k, ks0, ks1, ks2, vt, o, ldo, B, H, hd, N, Tk, Tkpad, scale, stream)
-            B, H, hd, N, Tk = a[11], a[12], a[13], a[14], a[15]
+            # (q, qs0, qs1, qs2, k, ks0, ks1, ks2, vt, [vt_bs,] o, ldo, B, H, hd, N, Tk, Tkpad, scale, stream)
+            B, H, hd, N, Tk = a[11 + sh], a[12 + sh], a[13 + sh], a[14 + sh], a[15 + sh]
             e0, e1 = ev(), ev()
-            e0.record(); rc = _att(*a); e1.record()
+            e0.record(); rc = fn(*a); e1.record()
             log.append(("attention", f"B{B} H{H} N{N} Tk{Tk}", 4.0 * B * H * N * Tk * hd, e0, e1))
             return rc
         return f
