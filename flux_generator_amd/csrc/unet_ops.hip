@@ -5,10 +5,9 @@
 namespace {
 
 // nn.LayerNorm(dims) with affine weight/bias, eps 1e-5 (TransformerBlock.norm1/2/3,
-// stable_diffusion/.../unet.py:45,50,57).  WPR waves share a row (NCH 16-byte chunks per lane): at the UNet's widths a row
-// is 80 .. 160 chunks, so one wave per row left 3 dependent loads per lane and, at 4096 rows, 16 waves per CU to hide them
-// (10.5 us for 21 MB = 2 TB/s); two or four waves per row read it in one round and put 2-4 x the waves in flight.
-// The row statistics cross the waves through LDS in a fixed order (deterministic).
+// stable_diffusion/.../unet.py:45,50,57).  WPR waves share a row (NCH 16-byte chunks per lane); the launcher uses more than
+// one wave per row only for short inputs (see run_layernorm).  The row statistics cross the waves through LDS in a fixed
+// order (deterministic).
 template <int NCH, int WPR>
 __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __restrict__ x,
                                                                bf16_t* __restrict__ out,
@@ -39,13 +38,17 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __r
     for (int i = 1; i < WPR; ++i) t += r[w0 + i];
     return t;
   };
-  // gamma / beta do not depend on the statistics: request them with the row
-  u32x4 gw[NCH], bw[NCH];
+  // gamma / beta do not depend on the statistics: the multi-wave form (short inputs, latency-bound) requests them with
+  // the row; one wave per row (large grids, bandwidth-bound) reads them where they are used and keeps the registers
+  constexpr bool EARLY = WPR > 1;
+  u32x4 gw[EARLY ? NCH : 1], bw[EARLY ? NCH : 1];
+  if constexpr (EARLY) {
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = min(lane + i * LPR, nchunk - 1);
-    gw[i] = *((const u32x4*)gamma + c);
-    bw[i] = beta ? *((const u32x4*)beta + c) : u32x4{0, 0, 0, 0};
+    for (int i = 0; i < NCH; ++i) {
+      const int c = min(lane + i * LPR, nchunk - 1);
+      gw[i] = *((const u32x4*)gamma + c);
+      bw[i] = beta ? *((const u32x4*)beta + c) : u32x4{0, 0, 0, 0};
+    }
   }
   float v[NCH][8];
   float sum = 0.f;
@@ -85,11 +88,18 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16_t* __r
   for (int i = 0; i < NCH; ++i) {
     int c = lane + i * LPR;
     if (c < nchunk) {
-      u32x4 o;
+      u32x4 o, g4, b4;
+      if constexpr (EARLY) {
+        g4 = gw[i];
+        b4 = bw[i];
+      } else {
+        g4 = *((const u32x4*)gamma + c);
+        b4 = beta ? *((const u32x4*)beta + c) : u32x4{0, 0, 0, 0};
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        o[e] = pack_bf16x2((v[i][2 * e] - mean) * rstd * bf_lo(gw[i][e]) + bf_lo(bw[i][e]),
-                           (v[i][2 * e + 1] - mean) * rstd * bf_hi(gw[i][e]) + bf_hi(bw[i][e]));
+        o[e] = pack_bf16x2((v[i][2 * e] - mean) * rstd * bf_lo(g4[e]) + bf_lo(b4[e]),
+                           (v[i][2 * e + 1] - mean) * rstd * bf_hi(g4[e]) + bf_hi(b4[e]));
       *((u32x4*)orow + c) = o;
     }
   }
@@ -201,17 +211,25 @@ static int run_layernorm(const void* x, void* out, int64_t rows, int D, const vo
   if (!x || !out || !gamma || (!beta && !rms) || rows < 1 || D < 8 || D % 8 || D > 4096) return FLUXHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = D / 8;
-  // waves per row: enough lanes that a row is read in one round up to D = 2048 (T5's 4096: two rounds of four waves)
-  const int wpr = nchunk > 128 ? 4 : nchunk > 64 ? 2 : 1;
+  // waves per row: one when the grid fills the chip anyway (the row's 2-3 chunk loads per lane are independent, and the
+  // cross-wave exchange costs two block barriers: 4096 x 1280 takes 6.0 us with one wave per row, 7.6 us with four -
+  // tools/ln_ab.py); two or four for short inputs, where more waves in flight hide the latency (512 x 4096, T5: 6.5 -> 3.8 us)
+  const int wpr = rows > 1536 ? 1 : nchunk > 128 ? 4 : nchunk > 64 ? 2 : 1;
   const int nch = (nchunk + 64 * wpr - 1) / (64 * wpr);
   dim3 grid((unsigned)((rows * wpr + 3) / 4)), block(256);
 #define LNA(NCH, WPR)                                                                             \
   hipLaunchKernelGGL((layernorm_affine_kernel<NCH, WPR>), grid, block, 0, s, (const bf16_t*)x,    \
                      (bf16_t*)out, (long long)rows, D, (const bf16_t*)gamma, (const bf16_t*)beta, eps, rms)
-  if (wpr == 1) LNA(1, 1);
-  else if (wpr == 2) LNA(1, 2);
-  else if (nch <= 1) LNA(1, 4);
-  else LNA(2, 4);
+  if (wpr == 4) {
+    if (nch <= 1) LNA(1, 4);
+    else LNA(2, 4);
+  } else if (wpr == 2) LNA(1, 2);
+  else if (nch <= 1) LNA(1, 1);
+  else if (nch <= 2) LNA(2, 1);
+  else if (nch <= 3) LNA(3, 1);
+  else if (nch <= 4) LNA(4, 1);
+  else if (nch <= 6) LNA(6, 1);
+  else LNA(8, 1);
 #undef LNA
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }

@@ -46,4 +46,8 @@ BENCH_FORCE_DIST=1 $B --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail 
 python tools/bench_sdxl.py 2>/dev/null | tail -1 > $O/bench_r03_sdxl_b16.json
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p7 -o kt -- python $R/tools/bench_sdxl.py >/dev/null 2>&1 )
 python tools/prof_summary.py $(find /tmp/p7 -name "*kernel_stats.csv" | head -1) $O/r03_kernel_stats_sdxl_b16.csv > /dev/null
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p8 -o kt -- python $R/bench.py --fp8 --steps 2 --warmup 1 --profile-only >/dev/null 2>&1 )
+python tools/prof_summary.py $(find /tmp/p8 -name "*kernel_stats.csv" | head -1) $O/r03_kernel_stats_fp8_b4_1024.csv > /dev/null
+bash tools/fp8_pmc.sh > /dev/null 2>&1      # -> $O/r03_fp8_gemm_pmc.txt
+python tools/prof_unet_layers.py 2>&1 | grep -v amdgpu > $O/r03_unet_layers_b16.txt
 head -12 $O/r03_kernel_stats_bench_n1.csv; head -8 $O/r03_hbm_traffic_pmc.csv; cat $O/r03_splitk_phase_trace.txt; cat $O/r03_norm_bench.txt
