@@ -64,6 +64,8 @@ SIGNATURES = {
     "fluxhip_gemm_set_splitk_mode": (c_int, [c_int]),
     "fluxhip_attention_set_variant": (c_int, [c_int]),
     "fluxhip_gemm_rs_launches": (C.c_int64, []),
+    "fluxhip_gemm_set_lean": (c_int, [c_int]),
+    "fluxhip_gemm_lean_launches": (C.c_int64, []),
     "fluxhip_set_workspace": (c_int, [c_void_p, c_int64]),
     "fluxhip_conv2d_bf16": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_void_p]),
     "fluxhip_conv2d_small": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),

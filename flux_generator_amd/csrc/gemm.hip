@@ -28,7 +28,11 @@ struct TileCfg {
   void (*conv_x3)(const GemmParams);
   void (*dense_f8)(const GemmParams);   // FLAG_FP8 (e4m3 x e4m3 on the 16x16x128 block-scaled MFMA); simple-ring and ping-pong tiles
   int wm = 1;                           // waves along M (rows per wave = bm / wm)
-  void (*dense_rs)(const GemmParams) = nullptr;   // FLAG_RS (split-K reduce-scatter hand-off) variant: 256 x 256 / 256 x 192 ping-pong
+  void (*dense_rs)(const GemmParams) = nullptr;   // FLAG_RS | FLAG_LEAN (split-K reduce-scatter hand-off) variant: 256 x 256 / 256 x 192 ping-pong
+  void (*dense_lean)(const GemmParams) = nullptr; // FLAG_LEAN: the same dense kernel with only the transformer-block epilogues compiled in (lean_ok)
+  void (*dense_f8_lean)(const GemmParams) = nullptr;   // FLAG_FP8 | FLAG_LEAN: the four transformer-block epilogues (runtime switch)
+  int lean_epi = -1;                              // >= 0: the lean kernel has exactly this epilogue compiled in
+  int rs_epi = -1;                                //       (and the reduce-scatter kernel this one)
 };
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE, int FLAGS = 0>
@@ -59,8 +63,28 @@ constexpr TileCfg make_cfg_x3_f8() {
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE, int EXTRA = 0>
-constexpr TileCfg with_rs(TileCfg c) {
-  c.dense_rs = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_RS | EXTRA>;
+constexpr TileCfg with_rs(TileCfg c) {      // split-K launches are the K >= 5120 projections back into the residual stream
+  c.dense_rs = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_RS | FLAG_LEAN | ((EPI_GATE_RES + 1) << 8) | EXTRA>;
+  c.rs_epi = EPI_GATE_RES;
+  return c;
+}
+// Lean twins of the tiles the Flux / transformer-block launches run on.  The epilogue of gemm_nt_kernel is one runtime switch
+// over every fused form any caller needs (9 activations / gates, row or column bias, addvec, float32 output, the direct-store
+// path for unaligned operands, the split-K chain); code that is merely PRESENT costs the launches that never take it - the
+// reduce-scatter hand-off compiled into the shared kernel cost the non-split launches 2-4 %.  A FLAG_LEAN
+// instantiation keeps bias + {none, GELU-tanh, gate-residual, split-GELU} on the LDS-transposed epilogue and nothing else.
+// (A second twin with the four epilogues behind the runtime switch, for the launches of the multi-round plans - Flux-dev
+//  1024^2, batch 4 - the single-epilogue kernels do not match, measured level with the generic kernel there and is not built.)
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE, int EPI>
+constexpr TileCfg with_lean(TileCfg c) {
+  c.dense_lean = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_LEAN | ((EPI + 1) << 8)>;
+  c.lean_epi = EPI;
+  return c;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
+constexpr TileCfg with_lean_f8(TileCfg c) {   // fp8: at C5's batch the 256x224 / 256x256 tiles serve several epilogues each
+  c.dense_f8_lean = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_FP8 | FLAG_LEAN>;
   return c;
 }
 
@@ -113,11 +137,11 @@ const TileCfg kCfgs[] = {
     make_cfg<256, 224, 4, 2, 2, 5>(),     // 44: cfg 37 "
     make_cfg<256, 192, 4, 2, 2, 5>(),     // 45: cfg 38 "
     make_cfg<256, 128, 4, 2, 3, 5>(),     // 46: cfg 41 "
-    make_cfg_x3<128, 128, 2, 4, 3, 5>(),     // 47: cfg 40 "
+    with_lean<128, 128, 2, 4, 3, 5, EPI_GATE_RES>(make_cfg_x3<128, 128, 2, 4, 3, 5>()),     // 47: cfg 40 "
     make_cfg<256, 256, 4, 2, 2, 5, 1>(),  // 48: cfg 43 with phase stamps (diagnostic: fluxhip_gemm_set_trace, tools/gemm_phase_trace.py)
-    with_rs<256, 256, 4, 2, 2, 6>(make_cfg_x3_f8<256, 256, 4, 2, 2, 6>()),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
-    make_cfg_f8<256, 224, 4, 2, 2, 6>(),     // 50: cfg 44 "
-    with_rs<256, 192, 4, 2, 2, 6>(make_cfg_f8<256, 192, 4, 2, 2, 6>()),     // 51: cfg 45 "
+    with_lean_f8<256, 256, 4, 2, 2, 6>(with_lean<256, 256, 4, 2, 2, 6, EPI_GELU_TANH>(with_rs<256, 256, 4, 2, 2, 6>(make_cfg_x3_f8<256, 256, 4, 2, 2, 6>()))),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
+    with_lean_f8<256, 224, 4, 2, 2, 6>(with_lean<256, 224, 4, 2, 2, 6, EPI_SPLIT_GELU>(make_cfg_f8<256, 224, 4, 2, 2, 6>())),     // 50: cfg 44 "
+    with_lean<256, 192, 4, 2, 2, 6, EPI_BIAS>(with_rs<256, 192, 4, 2, 2, 6>(make_cfg_f8<256, 192, 4, 2, 2, 6>())),     // 51: cfg 45 "
     make_cfg_f8<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
     make_cfg_f8<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
     make_cfg_f8<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
@@ -126,7 +150,7 @@ const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-bool g_attr_set[kNumCfgs][6] = {};
+bool g_attr_set[kNumCfgs][8] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
 // Tile choice: a time model per tile, fitted to tools/gemm_tune.py sweeps.
@@ -219,6 +243,9 @@ int g_num_cus = 0;                                    // CUs of the bound device
 // FLUXHIP_SPLITK=chain (or fluxhip_gemm_set_splitk_mode(1)) keeps every split-K launch on the chain (A/B runs, diagnostics)
 bool g_rs_enabled = [] { const char* e = getenv("FLUXHIP_SPLITK"); return !(e && e[0] == 'c'); }();
 long long g_rs_launches = 0;
+// FLUXHIP_LEAN=0 (or fluxhip_gemm_set_lean(0)): every launch on the generic kernels (A/B runs, tests)
+bool g_lean_enabled = [] { const char* e = getenv("FLUXHIP_LEAN"); return !(e && e[0] == '0'); }();
+long long g_lean_launches = 0;
 
 // Can a split-K launch of `cfg` with S splits over `tiles` output tiles use the reduce-scatter hand-off?
 bool rs_ok(int cfg, int S, long long tiles, bool conv, bool x3, bool f8) {
@@ -326,6 +353,27 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     wide = wide && a16(p.C2) && p.n_split % 8 == 0 && p.ldc2 % 8 == 0 && p.c2_coloff % 8 == 0 && p.c2_bstride % 8 == 0;
   p.wide_epi = wide;
   p.splits = splits;
+  // what a FLAG_LEAN instantiation can do (with_lean above): the transformer-block epilogues on the LDS-transposed path
+  const bool lean_any = !conv && !x3 && wide && !p.addvec && !p.row_bias && !p.out_f32 &&
+                        (p.epi == EPI_BIAS || p.epi == EPI_GELU_TANH || p.epi == EPI_GATE_RES || p.epi == EPI_SPLIT_GELU);
+  const bool lean_ok = lean_any && !f8;
+  const bool lean_on = g_lean_enabled;
+  auto use = [&](void (*k)(const GemmParams), int slot_) {      // a variant kernel of this tile: dynamic LDS attribute once
+    if (!g_attr_set[cfg_idx][slot_]) {
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess) return false;
+      g_attr_set[cfg_idx][slot_] = true;
+    }
+    fn = k;
+    return true;
+  };
+  void (*const generic)(const GemmParams) = fn;
+  if (splits == 1 && lean_on) {
+    bool ok = true;
+    if (lean_ok && c.dense_lean && p.epi == c.lean_epi) ok = use(c.dense_lean, 6);
+    else if (f8 && lean_any && c.dense_f8_lean) ok = use(c.dense_f8_lean, 7);
+    if (!ok) return FLUXHIP_ELAUNCH;
+    g_lean_launches += fn != generic;
+  }
   if (splits > 1) {
     const long long tiles = (long long)tm_total * p.tiles_n;
     if (splits > (f8 ? p.K / 128 : (x3 ? 3 : 1) * (p.K / 64)) || tiles > kSkMaxTiles ||
@@ -333,16 +381,10 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
       return FLUXHIP_EINVAL;                        // no (or too small a) split-K workspace
     p.sk_flag = (int*)g_ws;
     p.sk_part = (float*)(g_ws + kSkFlagBytes);
-    p.sk_mode = (wide && !p.addvec && rs_ok(cfg_idx, splits, tiles, conv, x3, f8)) ? 1 : 0;   // (the direct-store epilogue is not ownership-aware)
+    p.sk_mode = (lean_ok && p.epi == c.rs_epi && rs_ok(cfg_idx, splits, tiles, conv, x3, f8)) ? 1 : 0;   // (the reduce-scatter kernels are lean: LDS-transposed epilogue, transformer-block epilogues)
     p.sk_depart = p.sk_flag + kSkMaxTiles / 2;
     g_rs_launches += p.sk_mode != 0;
-    if (p.sk_mode) {
-      fn = c.dense_rs;
-      if (!g_attr_set[cfg_idx][5]) {
-        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess) return FLUXHIP_ELAUNCH;
-        g_attr_set[cfg_idx][5] = true;
-      }
-    }
+    if (p.sk_mode && !use(c.dense_rs, 5)) return FLUXHIP_ELAUNCH;
   }
   dim3 grid(tm_total * p.tiles_n * splits), block(c.threads);
   hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);
@@ -500,6 +542,13 @@ extern "C" int fluxhip_gemm_set_splitk_mode(int mode) {
 }
 
 extern "C" int64_t fluxhip_gemm_rs_launches(void) { return g_rs_launches; }
+
+extern "C" int fluxhip_gemm_set_lean(int on) {
+  g_lean_enabled = on != 0;
+  return FLUXHIP_OK;
+}
+
+extern "C" int64_t fluxhip_gemm_lean_launches(void) { return g_lean_launches; }
 
 extern "C" int fluxhip_gemm_set_trace(void* buf) {
   g_trace = (unsigned long long*)buf;

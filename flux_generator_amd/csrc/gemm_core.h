@@ -140,6 +140,7 @@ enum GemmFlags : int {
   // they share the kernel (build-to-build A/B, tools/lib_ab.py: mlp0 87.1 -> 88.7 us, linear1 150.0 -> 153.0 us), so only the
   // tiles the picker splits (256 x 192, 256 x 256) carry a second kernel with it.
   FLAG_RS = 16,
+  FLAG_LEAN = 32,    // dense bf16 only: the epilogues, operands and hand-offs the Flux / transformer-block launches use, nothing else compiled in (see gemm.hip lean_ok)
 };
 
 template <int N>
@@ -187,7 +188,10 @@ void gemm_nt_kernel(const GemmParams p) {
   // and either hands the sum on (s < S-1) or runs the epilogue (s = S-1): a fixed summation order, so the
   // result is deterministic.  Block s only ever waits for a block with a LOWER block id, which the
   // dispatcher has already started, so the chain cannot deadlock even when the grid exceeds the chip.
-  const int S = p.splits;
+  // FLAG_LEAN: a non-RS lean kernel is never launched with a split (the chain code below folds away); a lean RS kernel is
+  // only ever launched in reduce-scatter mode
+  constexpr bool LEAN = (FLAGS & FLAG_LEAN) != 0;
+  const int S = (LEAN && (FLAGS & FLAG_RS) == 0) ? 1 : p.splits;
   int nblk = gridDim.x, bid = blockIdx.x, sidx = 0;
   // Reduce-scatter split-K (sk_mode 1, see the hand-off after the main loop) exchanges its partials through memory, so the
   // S blocks of a tile need not share an XCD — and should not: with K = 12288 / 15360 the main loop of the N = 3072
@@ -197,7 +201,7 @@ void gemm_nt_kernel(const GemmParams p) {
   // (split-major, N-tile, M-tile) order — 240 blocks: every XCD owns ONE K range, 6 N-tiles and all 5 M-tiles — so an XCD
   // reads a third of the activation panel (once per brick row) and its own weight panels: ~215 MB per launch.
   bool rs_map = false;
-  if constexpr ((FLAGS & FLAG_RS) != 0) rs_map = S > 1 && p.sk_mode != 0;
+  if constexpr ((FLAGS & FLAG_RS) != 0) rs_map = LEAN || (S > 1 && p.sk_mode != 0);
   int swz;
   if (rs_map) {
     const int T = nblk / S;
@@ -968,7 +972,7 @@ void gemm_nt_kernel(const GemmParams p) {
   static_assert(!RS_CAPABLE || (PP && !X3 && !F8 && AMODE == 0), "reduce-scatter split-K: ping-pong dense bf16 tiles");
   bool rs = false;
   if constexpr (RS_CAPABLE) {
-    if (S > 1 && p.sk_mode != 0) {
+    if (LEAN || (S > 1 && p.sk_mode != 0)) {
       rs = true;
       const bool by_rows = (MI % S) == 0;             // the launcher guarantees MI % S == 0 or NJ % S == 0
       if (by_rows) { oi_lo = sidx * (MI / S); oi_hi = oi_lo + MI / S; }
@@ -1043,7 +1047,7 @@ void gemm_nt_kernel(const GemmParams p) {
   // Mode 0, CHAIN.  Release / acquire at agent scope, executed by ONE lane per block: the release (buffer_wbl2) walks the
   // whole L2, and one per wave made the hand-off cost ~60 us per launch.  Every wave first waits for its
   // own stores (vmcnt(0)), the block barrier collects them, then lane 0 fences and moves the counter.
-  if (S > 1 && !rs) {
+  if (!(LEAN && RS_CAPABLE) && S > 1 && !rs) {
     f32x4* part = (f32x4*)(p.sk_part + (size_t)bid * (BM * BN)) + (size_t)wave * (MI * NJ) * 64 + lane;
     int* flag = p.sk_flag + bid;
     if (sidx > 0) {
@@ -1086,7 +1090,10 @@ void gemm_nt_kernel(const GemmParams p) {
   // residual on 8 consecutive columns and stores 16 B per lane = whole 128-byte lines per row.
   // Every fused epilogue starts from the bf16-rounded (acc + bias), so the LDS round trip is exact.
   // The direct path remains for float32 outputs and for operands that are not 16-byte aligned.
-  const int epi = p.epi;
+  // FLAG_LEAN kernels may also fix their ONE epilogue at compile time (FLAGS bits 8-11 = epilogue code + 1): every
+  // `epi ==` below folds and the kernel carries a single store path
+  constexpr int LEPI = (FLAGS >> 8) & 15;
+  const int epi = LEPI ? LEPI - 1 : p.epi;
   const float alpha = p.alpha;
   if constexpr (X3) {
     // FLAG_SPLIT epilogue: v = alpha * acc + bias (float32 bias, by column or by row) [+ residual (hi + lo planes)],
@@ -1154,7 +1161,7 @@ void gemm_nt_kernel(const GemmParams p) {
     return;
   }
   constexpr int NCH = WTN / 8;                      // 16-byte chunks per row of the wave's sub-tile
-  const bool wide = p.wide_epi != 0;
+  const bool wide = LEAN || p.wide_epi != 0;
   char* const my_lds = smem + wave * (WTM * WTN * 2);
   static_assert(BM * BN * 2 <= NSA * A_BYTES + NSW * B_BYTES, "epilogue staging must fit in the operand ring");
   if (wide) __builtin_amdgcn_s_barrier();           // every wave is done reading the last operand slots
@@ -1165,7 +1172,7 @@ void gemm_nt_kernel(const GemmParams p) {
   u32x2 bcol[NJ];
   float brow[MI];
   {
-    const bool colb = gBias && !p.row_bias, rowb = gBias && p.row_bias;
+    const bool colb = gBias && (LEAN || !p.row_bias), rowb = !LEAN && gBias && p.row_bias;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int n4 = min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4);
@@ -1211,11 +1218,11 @@ void gemm_nt_kernel(const GemmParams p) {
     dst = gC + (long long)b * c_bs + (long long)m * p.ldc + n;
     if (epi == EPI_GELU_TANH) {
       for (int r = 0; r < NV; ++r) v[r] = gelu_tanh_f(v[r]);
-    } else if (epi == EPI_SILU) {
+    } else if (!LEAN && epi == EPI_SILU) {
       for (int r = 0; r < NV; ++r) v[r] = silu_f(v[r]);
-    } else if (epi == EPI_QUICK_GELU) {
+    } else if (!LEAN && epi == EPI_QUICK_GELU) {
       for (int r = 0; r < NV; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
-    } else if (epi == EPI_GELU_ERF) {
+    } else if (!LEAN && epi == EPI_GELU_ERF) {
       for (int r = 0; r < NV; ++r) v[r] = gelu_erf_f(v[r]);
     } else if (epi == EPI_GATE_RES) {
       const uint32_t* rp = (const uint32_t*)(gRes + (long long)b * c_bs + (long long)m * p.ldc + n);
@@ -1233,7 +1240,7 @@ void gemm_nt_kernel(const GemmParams p) {
           v[r + 1] = bf_hi(rw) + v[r + 1];
         }
       }
-    } else if (epi == EPI_GEGLU) {   // out = res * gelu_erf(acc + bias)   (y_a * nn.gelu(y_b))
+    } else if (!LEAN && epi == EPI_GEGLU) {   // out = res * gelu_erf(acc + bias)   (y_a * nn.gelu(y_b))
       const uint32_t* rp = (const uint32_t*)(gRes + (long long)b * c_bs + (long long)m * p.ldc + n);
       for (int r = 0; r < NV; r += 2) {
         const uint32_t rw = rp[r >> 1];
@@ -1278,11 +1285,11 @@ void gemm_nt_kernel(const GemmParams p) {
       }
     };
     if constexpr (RS_CAPABLE) {
-      if (rs) phase_a(std::false_type{}, std::true_type{});          // (the launcher keeps addvec GEMMs on the chain)
+      if (LEAN || rs) phase_a(std::false_type{}, std::true_type{});          // (the launcher keeps addvec GEMMs on the chain)
       else if (p.addvec) phase_a(std::true_type{}, std::false_type{});
       else phase_a(std::false_type{}, std::false_type{});
     } else {
-      if (p.addvec) phase_a(std::true_type{}, std::false_type{});
+      if (!LEAN && p.addvec) phase_a(std::true_type{}, std::false_type{});
       else phase_a(std::false_type{}, std::false_type{});
     }
     if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_epiA)::"memory");

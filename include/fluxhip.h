@@ -96,6 +96,13 @@ int fluxhip_set_workspace(void* ws, int64_t bytes);
  * fluxhip_gemm_rs_launches: number of reduce-scatter launches issued so far by this process (tests, profiling). */
 int fluxhip_gemm_set_splitk_mode(int mode);
 int64_t fluxhip_gemm_rs_launches(void);
+/* Lean kernels.  The tiles the transformer-block launches run on also exist as instantiations with ONE epilogue compiled
+ * in (bias; bias + GELU-tanh; gate-residual; split-GELU) on the LDS-transposed store path and nothing else - no other
+ * activation, no row bias / addvec / float32 output, no split-K chain; a launch that fits one takes it (same arithmetic,
+ * bit-identical results; the shared kernel's unused code cost those launches 1-2 %).  fluxhip_gemm_set_lean(0) keeps every
+ * launch on the generic kernels (A/B timing, tests); fluxhip_gemm_lean_launches counts the launches that took a lean one. */
+int fluxhip_gemm_set_lean(int on);
+int64_t fluxhip_gemm_lean_launches(void);
 /* Diagnostic: device buffer of [blocks][waves][16] u64 that the phase-timed tile configurations fill with
  * summed s_memtime deltas per main-loop phase (7 phases, iteration count, whole-wave cycles and 100 MHz ticks, setup and epilogue cycles); NULL disables. */
 int fluxhip_gemm_set_trace(void* buf);

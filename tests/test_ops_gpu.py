@@ -156,6 +156,52 @@ def test_gemm_split_k_reduce_scatter(dev, cfg, S):
     assert torch.equal(again, outs[0])
 
 
+@pytest.mark.parametrize("cfg,epi,N,K", [(51, "bias", 9216, 3072), (49, "gelu", 12288, 3072), (47, "gate_res", 3072, 3072),
+                                            (50, "split_gelu", 21504, 3072), (51 | (3 << 8), "gate_res", 3072, 12288)])
+def test_gemm_lean_kernels_match_the_generic_ones(dev, cfg, epi, N, K):
+    """The single-epilogue (FLAG_LEAN) twins of the Flux plan's tiles: each of the five launch kinds of a batch-1 forward
+    (qkv, mlp0, attn.proj, linear1 with the split-GELU epilogue, the split-K 3 reduce-scatter projections) must take its lean
+    kernel and give the SAME BITS as the generic kernel; anything a lean kernel has no code for stays on the generic one."""
+    from flux_generator_amd import _lib, ops
+    from flux_generator_amd.ops import make_gemm_desc
+    lib = _lib.load()
+    M = 1280
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    res, gate = rnd(M, 3072, seed=4), rnd(3072, seed=5)
+
+    def run():
+        if epi == "split_gelu":      # linear1: q|k|v columns to one buffer, GELU(mlp) columns to another
+            c1 = torch.empty(M, 9216, dtype=BF, device=dev)
+            c2 = torch.zeros(M, 3072 + 12288, dtype=BF, device=dev)
+            d = make_gemm_desc([dict(A=x.data_ptr(), W=w.data_ptr(), bias=b.data_ptr(), C=c1.data_ptr(), M=M)], 1, N, K, K, 9216,
+                               ops.EPI_SPLIT_GELU, n_split=9216, C2=c2.data_ptr(), ldc2=3072 + 12288, c2_coloff=3072, tile_cfg=cfg)
+            ops.gemm(d)
+            return torch.cat([c1, c2], dim=1)
+        kw = dict(bias={}, gelu=dict(epi=ops.EPI_GELU_TANH), gate_res=dict(epi=ops.EPI_GATE_RES, res=res, gate=gate))[epi]
+        return ops.linear(x, w, b, tile_cfg=cfg, **kw)
+
+    n0 = int(lib.fluxhip_gemm_lean_launches()) + _rs_launches()
+    lean = run()
+    assert int(lib.fluxhip_gemm_lean_launches()) + _rs_launches() == n0 + 1, "the launch did not take its lean kernel"
+    assert lib.fluxhip_gemm_set_lean(0) == 0 and lib.fluxhip_gemm_set_splitk_mode(1 if cfg >> 8 else 0) == 0
+    try:
+        n1 = int(lib.fluxhip_gemm_lean_launches()) + _rs_launches()
+        generic = run()
+        assert int(lib.fluxhip_gemm_lean_launches()) + _rs_launches() == n1
+    finally:
+        assert lib.fluxhip_gemm_set_lean(1) == 0 and lib.fluxhip_gemm_set_splitk_mode(0) == 0
+    if cfg >> 8:      # split-K: reduce-scatter vs chain differ in fp32 summation order
+        assert rel_l2(lean, generic.float().cpu()) < 4e-3
+    else:
+        assert torch.equal(lean, generic)
+    # a launch the lean kernel has no code for (another activation) stays generic and correct
+    n2 = int(lib.fluxhip_gemm_lean_launches())
+    y = ops.linear(x, w, b, epi=ops.EPI_SILU, tile_cfg=cfg & 255)
+    assert int(lib.fluxhip_gemm_lean_launches()) == n2
+    lin = O.linear(x.float().cpu(), w.float().cpu(), b.float().cpu())
+    assert rel_l2(y, lin * torch.sigmoid(lin)) < TOL
+
+
 def test_gemm_split_k_tiles_without_rs_kernel_use_the_chain(dev):
     """Tiles without a FLAG_RS instantiation (e.g. 256 x 224, 128 x 256 ping-pong) split through the chain hand-off."""
     from flux_generator_amd import ops
