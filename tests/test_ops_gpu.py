@@ -568,3 +568,27 @@ def test_gemm_pingpong_falls_back_for_4gib_operands(dev):
                                 tile_cfg=cfg))
         assert rel_l2(out, ref) < 2e-3, cfg
     del big
+
+
+def test_gemm_picker_keeps_the_flux_plan(dev):
+    """The tile picker's time model was refitted on 111 shapes in round 3 (csrc/gemm.hip, kCands); the choices for the six
+    block GEMMs of the batch-1 Flux plan were established IN SITU (tools/plan_sweep.py) and are the constraint of that fit:
+    256x192 for qkv, 128x128 for attn.proj, 256x256 for mlp0, 256x224 for linear1, 256x192 split-K 3 (reduce-scatter) for the
+    two K >= 12288 projections.  Also: the mid-sized SDXL projection the old model mis-ranked now gets 128x256."""
+    import ctypes
+    from flux_generator_amd import _lib
+    from flux_generator_amd.ops import make_gemm_desc
+    lib = _lib.load()
+
+    def pick(groups, N, K):
+        d = make_gemm_desc([dict(A=0, W=0, C=0, M=m) for m in groups], 1, N, K, K, N)
+        c = lib.fluxhip_gemm_tile_cfg(ctypes.byref(d))
+        return c & 255, c >> 8
+
+    assert pick([256, 1024], 9216, 3072) == (51, 1)
+    assert pick([256, 1024], 3072, 3072) == (47, 1)
+    assert pick([256, 1024], 12288, 3072) == (49, 1)
+    assert pick([256, 1024], 3072, 12288) == (51, 3)
+    assert pick([1280], 21504, 3072) == (50, 1)
+    assert pick([1280], 3072, 15360) == (51, 3)
+    assert pick([4096], 1280, 1280) == (55, 1)
