@@ -688,6 +688,23 @@ void gemm_nt_kernel(const GemmParams p) {
         };
         // Only step 0 has to be in LDS before the first MFMA: waiting for step 1 as well made every CU of the
         // chip sit through a second 64-KiB fetch of the cold-start burst.  Step 1 is waited for where it is needed.
+        // FLAG_SPLIT (REUSE_HI): passes 0 and 1 of an operand step multiply the SAME activation plane (hi x hi, hi x lo), so the
+        // hi tile is staged once and read for two steps: activation slot 0 holds the current hi tile, slot 1 the current lo
+        // tile (pass 2), and the group issues two activation stages per three steps instead of three - a third less LDS-DMA
+        // and, for the implicit-GEMM loader, a third less address generation in a loop that runs at ~57 % of the MFMA rate
+        // because of exactly that work.  pk = pass of step kt (a split-K block may start mid-triple).
+        constexpr bool REUSE_HI = X3;
+        int pk = REUSE_HI ? kbase % 3 : 0;
+        if constexpr (REUSE_HI) {
+          const int j = pk == 0 ? 2 : 1;           // first step with another activation tile than step 0
+          stage(0, pk == 2);
+          if (j < nkt) {
+            stage(j, (pk + j) % 3 == 2);
+            wait_vmcnt<PA>();
+          } else {
+            wait_vmcnt<0>();
+          }
+        } else {
         stage(0, 0);
         if (nkt > 1) {
           stage(1, 1);
@@ -695,9 +712,10 @@ void gemm_nt_kernel(const GemmParams p) {
         } else {
           wait_vmcnt<0>();
         }
+        }
         __builtin_amdgcn_s_barrier();
-        read_both(0, 0);
-        int sa = 0, sw = 0;                        // ring slots of step kt
+        read_both(REUSE_HI ? (pk == 2) : 0, 0);
+        int sa = REUSE_HI ? (pk == 2) : 0, sw = 0; // ring slots of step kt
         if constexpr (F8) {
           // The same schedule with the loop rotated (first MFMA phase peeled): the fragments of step kt are read and
           // consumed inside ONE iteration.  As loop-carried values (read at the bottom for the next trip) hipcc kept
@@ -725,7 +743,7 @@ void gemm_nt_kernel(const GemmParams p) {
           __builtin_amdgcn_s_barrier();            // B2 of the last step (group 1's MFMA phase)
         } else
         for (int kt = 0; kt < nkt; ++kt) {
-          const int sa1 = sa ^ 1, sw1 = sw == 2 ? 0 : sw + 1;
+          const int sa1 = REUSE_HI ? (pk == 1) : sa ^ 1, sw1 = sw == 2 ? 0 : sw + 1;   // REUSE_HI: step kt + 1 is a pass 2 iff this is a pass 1
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           mma_both();
@@ -734,7 +752,15 @@ void gemm_nt_kernel(const GemmParams p) {
           __builtin_amdgcn_s_barrier();            // B1
           // (past the last step this re-reads a valid slot into registers nobody uses: keeps the body branch-free)
           read_both(sa1, sw1);
-          if (kt + 2 < nkt) stage(kt + 2, sa);
+          if constexpr (REUSE_HI) {
+            // pass 0: slot 0 is read again by step kt + 1, nothing to stage; pass 1: slot 0 has had its last reader
+            // (group 1 read step kt before B1) -> the next hi tile, needed at kt + 2; pass 2: slot 1 -> the next lo tile (kt + 3)
+            if (pk == 1) { if (kt + 2 < nkt) stage(kt + 2, 0); }
+            else if (pk == 2) { if (kt + 3 < nkt) stage(kt + 3, 1); }
+            pk = pk == 2 ? 0 : pk + 1;
+          } else {
+            if (kt + 2 < nkt) stage(kt + 2, sa);
+          }
           __builtin_amdgcn_s_barrier();            // B2
           sa = sa1;
           sw = sw1;
@@ -775,8 +801,10 @@ void gemm_nt_kernel(const GemmParams p) {
         }
         __builtin_amdgcn_s_barrier();
         int sa = 0, sw = 0;
+        int pk = X3 ? kbase % 3 : 0;               // FLAG_SPLIT: the activation slot of a step is its pass (see group 0)
         for (int kt = 0; kt < nkt; ++kt) {
           const int sw1 = sw == 2 ? 0 : sw + 1, sw2 = sw1 == 2 ? 0 : sw1 + 1;
+          if constexpr (X3) sa = pk == 2;
           read_both(sa, sw);
           if (kt + 2 < nkt) {
             stage(kt + 2, sw2);
@@ -792,6 +820,7 @@ void gemm_nt_kernel(const GemmParams p) {
           __builtin_amdgcn_s_barrier();            // B2
           sa ^= 1;
           sw = sw1;
+          if constexpr (X3) pk = pk == 2 ? 0 : pk + 1;
         }
       }
     } else if constexpr (PIPEX >= 4) {
