@@ -31,6 +31,7 @@ struct TileCfg {
   void (*dense_rs)(const GemmParams) = nullptr;   // FLAG_RS | FLAG_LEAN (split-K reduce-scatter hand-off) variant: 256 x 256 / 256 x 192 ping-pong
   void (*dense_lean)(const GemmParams) = nullptr; // FLAG_LEAN: the same dense kernel with only the transformer-block epilogues compiled in (lean_ok)
   void (*dense_f8_lean)(const GemmParams) = nullptr;   // FLAG_FP8 | FLAG_LEAN: the four transformer-block epilogues (runtime switch)
+  void (*dense_pair)(const GemmParams) = nullptr;      // FLAG_LEAN with EPI_GEGLU_PAIR compiled in (the UNet's fused GEGLU Linears)
   int lean_epi = -1;                              // >= 0: the lean kernel has exactly this epilogue compiled in
   int rs_epi = -1;                                //       (and the reduce-scatter kernel this one)
 };
@@ -82,6 +83,11 @@ constexpr TileCfg with_lean(TileCfg c) {
   return c;
 }
 
+template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
+constexpr TileCfg with_pair(TileCfg c) {      // EPI_GEGLU_PAIR exists in these instantiations only (no generic kernel carries it)
+  c.dense_pair = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_LEAN | ((EPI_GEGLU_PAIR + 1) << 8)>;
+  return c;
+}
 template <int BM, int BN, int WM, int WN, int NSTAGE, int PIPE>
 constexpr TileCfg with_lean_f8(TileCfg c) {   // fp8: at C5's batch the 256x224 / 256x256 tiles serve several epilogues each
   c.dense_f8_lean = gemm_nt_kernel<BM, BN, WM, WN, 0, NSTAGE, PIPE, FLAG_FP8 | FLAG_LEAN>;
@@ -139,18 +145,18 @@ const TileCfg kCfgs[] = {
     make_cfg<256, 128, 4, 2, 3, 5>(),     // 46: cfg 41 "
     with_lean<128, 128, 2, 4, 3, 5, EPI_GATE_RES>(make_cfg_x3<128, 128, 2, 4, 3, 5>()),     // 47: cfg 40 "
     make_cfg<256, 256, 4, 2, 2, 5, 1>(),  // 48: cfg 43 with phase stamps (diagnostic: fluxhip_gemm_set_trace, tools/gemm_phase_trace.py)
-    with_lean_f8<256, 256, 4, 2, 2, 6>(with_lean<256, 256, 4, 2, 2, 6, EPI_GELU_TANH>(with_rs<256, 256, 4, 2, 2, 6>(make_cfg_x3_f8<256, 256, 4, 2, 2, 6>()))),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
+    with_pair<256, 256, 4, 2, 2, 6>(with_lean_f8<256, 256, 4, 2, 2, 6>(with_lean<256, 256, 4, 2, 2, 6, EPI_GELU_TANH>(with_rs<256, 256, 4, 2, 2, 6>(make_cfg_x3_f8<256, 256, 4, 2, 2, 6>())))),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
     with_lean_f8<256, 224, 4, 2, 2, 6>(with_lean<256, 224, 4, 2, 2, 6, EPI_SPLIT_GELU>(make_cfg_f8<256, 224, 4, 2, 2, 6>())),     // 50: cfg 44 "
     with_lean<256, 192, 4, 2, 2, 6, EPI_BIAS>(with_rs<256, 192, 4, 2, 2, 6>(make_cfg_f8<256, 192, 4, 2, 2, 6>())),     // 51: cfg 45 "
     make_cfg_f8<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
     make_cfg_f8<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
     make_cfg_f8<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
-    make_cfg_x3_f8<128, 256, 2, 4, 2, 6>(),     // 55: 128x256, ping-pong
+    with_pair<128, 256, 2, 4, 2, 6>(make_cfg_x3_f8<128, 256, 2, 4, 2, 6>()),     // 55: 128x256, ping-pong
     with_rs<256, 192, 4, 2, 2, 6, 1>(make_cfg<256, 192, 4, 2, 2, 6, 1>()),        // 56: cfg 51 with stamps around the main loop, the split-K reduce-scatter segments and the epilogue (diagnostic)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-bool g_attr_set[kNumCfgs][8] = {};
+bool g_attr_set[kNumCfgs][9] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
 // Tile choice: a time model per tile, fitted to tools/gemm_tune.py sweeps.
@@ -372,6 +378,10 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     return true;
   };
   void (*const generic)(const GemmParams) = fn;
+  if (p.epi == EPI_GEGLU_PAIR) {                  // lives in its own instantiations: no generic fallback
+    if (conv || x3 || f8 || splits != 1 || !wide || p.addvec || p.row_bias || p.out_f32 || !c.dense_pair || p.N % 32) return FLUXHIP_EINVAL;
+    if (!use(c.dense_pair, 8)) return FLUXHIP_ELAUNCH;
+  } else
   if (splits == 1 && lean_on) {
     bool ok = true;
     if (lean_ok && c.dense_lean && p.epi == c.lean_epi) ok = use(c.dense_lean, 6);
@@ -465,6 +475,13 @@ extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
   if (int rc = params_from_desc(d, p, 64)) return rc;
   const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
   int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K);
+  if (d->epi == FLUXHIP_EPI_GEGLU_PAIR && d->tile_cfg <= 0) {
+    // the pair epilogue exists for 256x256 and 128x256 only: the large tile once it fills most of the chip
+    long long t49 = 0;
+    for (int g = 0; g < d->ngroups; ++g) t49 += (long long)((gm[g] + 255) / 256) * d->nbatch;
+    t49 *= (d->N + 255) / 256;
+    cfg = t49 >= 192 ? 49 : 55;
+  }
   return launch(p, cfg, false, (hipStream_t)stream);
 }
 

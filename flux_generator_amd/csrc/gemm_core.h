@@ -33,6 +33,8 @@ enum GemmEpi : int {
   EPI_GEGLU = 5,      // C = res * gelu_erf(acc + bias)       (UNet GEGLU: linear1(y) * gelu(linear2(y)))
   EPI_QUICK_GELU = 6, // C = v * sigmoid(1.702 v), v = acc + bias   (CLIP "quick_gelu", flux/clip.py:9)
   EPI_GELU_ERF = 7,   // C = gelu_erf(acc + bias)   (nn.gelu: OpenCLIP text towers of SD 2.1 / SDXL, stable_diffusion/.../clip.py:11)
+  EPI_GEGLU_PAIR = 8, // lean kernels only: W holds [value rows | gate rows] interleaved in blocks of 16, C[m][16 f + c] = v * gelu_erf(g) with
+                      // v / g = column 32 f + c / 32 f + 16 + c of (acc + bias): the two GEGLU Linears of the UNet as ONE launch, N / 2 outputs
 };
 
 struct GemmGroup {
@@ -1322,6 +1324,28 @@ void gemm_nt_kernel(const GemmParams p) {
       else phase_a(std::false_type{}, std::false_type{});
     }
     if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_epiA)::"memory");
+    if constexpr (LEPI == EPI_GEGLU_PAIR + 1) {
+      // phase B, pair form: out chunk oc of a row = value chunk (4 f + h) * gelu_erf(gate chunk (4 f + 2 + h)), f = oc / 2, h = oc & 1
+      static_assert(NJ % 2 == 0, "GEGLU pair epilogue: an even number of 16-column fragments per wave");
+      constexpr int NOC = NCH / 2;
+      constexpr int NITP = (WTM * NOC + 63) / 64;
+      const int nhalf = N >> 1;
+#pragma unroll 4
+      for (int t = 0; t < NITP; ++t) {
+        const int idx = t * 64 + lane;
+        const int row = idx / NOC, oc = idx - row * NOC;
+        const int ca = (oc >> 1) * 4 + (oc & 1);
+        const int m = m0 + wm * WTM + row, nout = ((n0 + wn * WTN) >> 1) + (oc >> 1) * 16 + (oc & 1) * 8;
+        if (row >= WTM || m >= Mg || nout >= nhalf) continue;
+        const u32x4 xa = *(const u32x4*)(my_lds + row * (NCH * 16) + cswz(ca, row) * 16);
+        const u32x4 xg = *(const u32x4*)(my_lds + row * (NCH * 16) + cswz(ca + 2, row) * 16);
+        u32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o[r] = pack_bf16x2(bf_lo(xa[r]) * rbf(gelu_erf_f(bf_lo(xg[r]))), bf_hi(xa[r]) * rbf(gelu_erf_f(bf_hi(xg[r]))));
+        *(u32x4*)(gC + (long long)b * c_bs + (long long)m * p.ldc + nout) = o;
+      }
+    } else {
     // phase B: LDS -> 8 consecutive columns per lane -> global
     constexpr int NIT = (WTM * NCH + 63) / 64;
     // reduce-scatter split-K: the owned rows [r_lo, r_lo + nr) x chunks [c_lo, c_lo + ncw) of the wave's sub-tile only
@@ -1356,6 +1380,7 @@ void gemm_nt_kernel(const GemmParams p) {
         dst = gC + (long long)b * c_bs + (long long)m * p.ldc + n8;
       }
       *(u32x4*)dst = o;
+    }
     }
   } else {
 #pragma unroll

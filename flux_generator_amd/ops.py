@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import Fp8Scales, GemmDesc, GemmX3Desc
 
-EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU, EPI_QUICK_GELU, EPI_GELU_ERF = 0, 1, 2, 3, 4, 5, 6, 7
+EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_GEGLU_PAIR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 BF16 = torch.bfloat16
 
 
@@ -76,11 +76,23 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, e
     K = x.shape[-1]
     N = w.shape[0]
     M = x.numel() // K
+    Nout = N // 2 if epi == EPI_GEGLU_PAIR else N      # the pair epilogue multiplies value and gate columns: N / 2 outputs
     if out is None:
-        out = torch.empty(*x.shape[:-1], N, dtype=BF16, device=x.device)
+        out = torch.empty(*x.shape[:-1], Nout, dtype=BF16, device=x.device)
     g = dict(A=_p(x), W=_p(w), bias=_p(b), C=_p(out), res=_p(res), gate=_p(gate), M=M)
-    gemm(make_gemm_desc([g], 1, N, K, K, N, epi, tile_cfg=tile_cfg))
+    gemm(make_gemm_desc([g], 1, N, K, K, Nout, epi, tile_cfg=tile_cfg))
     return out
+
+
+def interleave_geglu(value: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    """[value rows | gate rows] of the two GEGLU Linears (weights [N, K] or biases [N]) interleaved in blocks of 16 rows: the
+    operand layout of EPI_GEGLU_PAIR (include/fluxhip.h)."""
+    n = value.shape[0]
+    if n % 16 or value.shape != gate.shape:
+        raise FluxHipError("GEGLU halves must have the same shape and a multiple of 16 rows")
+    v = value.reshape(n // 16, 16, *value.shape[1:])
+    g = gate.reshape(n // 16, 16, *gate.shape[1:])
+    return torch.stack([v, g], dim=1).reshape(2 * n, *value.shape[1:]).contiguous()
 
 
 def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,

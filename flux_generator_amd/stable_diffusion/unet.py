@@ -15,12 +15,13 @@ with fp32 accumulation (stated in tests/test_sd_gpu.py).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple, Union
 
 import torch
 
 from .. import _lib, ops
-from ..ops import EPI_GATE_RES, EPI_GEGLU, FluxHipError, make_gemm_desc
+from ..ops import EPI_GATE_RES, EPI_GEGLU, EPI_GEGLU_PAIR, FluxHipError, interleave_geglu, make_gemm_desc
 from .config import UNetConfig
 
 BF16 = torch.bfloat16
@@ -185,6 +186,14 @@ class UNetModel:
             if k.endswith(".attn1.query_proj.weight"):
                 b = k[: -len(".query_proj.weight")]
                 F[f"{b}.qk"] = torch.cat([P[k], P[f"{b}.key_proj.weight"]], dim=0).contiguous()
+        # GEGLU (unet.py:74-78: linear1(y) * gelu(linear2(y))): both Linears as ONE launch with the pair epilogue - value and
+        # gate rows interleaved in blocks of 16, the product formed in the epilogue (include/fluxhip.h, FLUXHIP_EPI_GEGLU_PAIR)
+        fuse_geglu = os.environ.get("FLUXHIP_UNET_GEGLU", "pair") != "split"      # "split": the two-launch form (A/B timing)
+        for k in list(P):
+            if fuse_geglu and k.endswith(".linear2.weight") and k[: -len("2.weight")] + "1.weight" in P:
+                b = k[: -len(".linear2.weight")]
+                F[f"{b}.geglu.w"] = interleave_geglu(P[f"{b}.linear1.weight"], P[k])
+                F[f"{b}.geglu.b"] = interleave_geglu(P[f"{b}.linear1.bias"], P[f"{b}.linear2.bias"])
         # cross-attention: K and V^T depend on the text only -> all layers of one width are projected together
         # (text_kv); group = (channels, encoder width), layer slot = row offset inside the concatenated weights
         groups: Dict[Tuple[int, int], list] = {}
@@ -289,8 +298,11 @@ class UNetModel:
             n = ops.layernorm_affine(y, W[f"{b}.norm2.weight"], W[f"{b}.norm2.bias"])
             y = self._mha(f"{b}.attn2", H, y, n, mem, Tk)
             n = ops.layernorm_affine(y, W[f"{b}.norm3.weight"], W[f"{b}.norm3.bias"])
-            a = ops.linear(n, W[f"{b}.linear1.weight"], W[f"{b}.linear1.bias"])
-            g = ops.linear(n, W[f"{b}.linear2.weight"], W[f"{b}.linear2.bias"], epi=EPI_GEGLU, res=a)
+            if f"{b}.geglu.w" in self._fused:
+                g = ops.linear(n, self._fused[f"{b}.geglu.w"], self._fused[f"{b}.geglu.b"], epi=EPI_GEGLU_PAIR)
+            else:
+                a = ops.linear(n, W[f"{b}.linear1.weight"], W[f"{b}.linear1.bias"])
+                g = ops.linear(n, W[f"{b}.linear2.weight"], W[f"{b}.linear2.bias"], epi=EPI_GEGLU, res=a)
             y = ops.linear(g, W[f"{b}.linear3.weight"], W[f"{b}.linear3.bias"], epi=EPI_GATE_RES, res=y)
         out = ops.linear(y, W[f"{p}.proj_out.weight"], W[f"{p}.proj_out.bias"], epi=EPI_GATE_RES,
                          res=x.view(B, Hh * Ww, C))

@@ -34,7 +34,11 @@ enum {
   FLUXHIP_EPI_SILU = 4,       /* C = silu(A W^T + b)                                            */
   FLUXHIP_EPI_GEGLU = 5,      /* C = res * gelu_erf(A W^T + b)       UNet GEGLU (unet.py:74-78) */
   FLUXHIP_EPI_QUICK_GELU = 6, /* C = v * sigmoid(1.702 v)            CLIP quick_gelu (flux/clip.py:9) */
-  FLUXHIP_EPI_GELU_ERF = 7    /* C = gelu_erf(A W^T + b)             nn.gelu: OpenCLIP text towers (stable_diffusion/.../clip.py:11) */
+  FLUXHIP_EPI_GELU_ERF = 7,   /* C = gelu_erf(A W^T + b)             nn.gelu: OpenCLIP text towers (stable_diffusion/.../clip.py:11) */
+  FLUXHIP_EPI_GEGLU_PAIR = 8  /* the two Linears of the UNet GEGLU (unet.py:74-78) as ONE launch: W = [N][K] with the value rows and the gate rows
+                               * interleaved in blocks of 16 (rows 32 f .. 32 f + 15 = value rows 16 f .., rows 32 f + 16 .. = gate rows 16 f ..),
+                               * bias likewise, C = [M][N / 2]: C[m][16 f + c] = v * gelu_erf(g).  N % 32 == 0, ldc >= N / 2; bit-identical to
+                               * FLUXHIP_EPI_BIAS followed by FLUXHIP_EPI_GEGLU */
 };
 
 /* One operand group of a (possibly grouped) GEMM. Two groups share N, K, the epilogue and the

@@ -592,3 +592,27 @@ def test_gemm_picker_keeps_the_flux_plan(dev):
     assert pick([1280], 21504, 3072) == (50, 1)
     assert pick([1280], 3072, 15360) == (51, 3)
     assert pick([4096], 1280, 1280) == (55, 1)
+
+
+@pytest.mark.parametrize("M,C", [(4096, 1280), (600, 320), (16384, 640), (130, 64)])
+def test_gemm_geglu_pair_epilogue(dev, M, C):
+    """EPI_GEGLU_PAIR: the two Linears of the UNet's GEGLU (stable_diffusion/.../unet.py:74-78) as one launch over interleaved
+    value / gate rows; must give the SAME BITS as linear1 followed by linear2 with the EPI_GEGLU epilogue (ragged M edges, both
+    tiles that carry the pair kernel), and agree with the float32 oracle; requests it cannot serve fail loudly."""
+    from flux_generator_amd import ops
+    K, N = C, 4 * C
+    x = rnd(M, K, seed=1)
+    w1, w2 = rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, K, seed=3, scale=K ** -0.5)
+    b1, b2 = rnd(N, seed=4), rnd(N, seed=5)
+    a = ops.linear(x, w1, b1)
+    two = ops.linear(x, w2, b2, epi=ops.EPI_GEGLU, res=a)
+    wp, bp = ops.interleave_geglu(w1, w2), ops.interleave_geglu(b1, b2)
+    for cfg in (0, 49, 55):
+        one = ops.linear(x, wp, bp, epi=ops.EPI_GEGLU_PAIR, tile_cfg=cfg)
+        assert one.shape == (M, N) and torch.equal(one, two), cfg
+    xf = x.float().cpu()
+    va = O.linear(xf, w1.float().cpu(), b1.float().cpu())
+    vg = O.linear(xf, w2.float().cpu(), b2.float().cpu())
+    assert rel_l2(two, va * torch.nn.functional.gelu(vg)) < TOL
+    with pytest.raises(ops.FluxHipError):
+        ops.linear(x, wp, bp, epi=ops.EPI_GEGLU_PAIR, tile_cfg=51)          # a tile without the pair kernel
