@@ -161,6 +161,15 @@ def rope_table(ids: torch.Tensor, axes_dim: Sequence[int], theta: float) -> torc
     return out
 
 
+def silu(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16(silu(x)) elementwise (fluxhip_silu_bf16)."""
+    _bf16c(x, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(_lib.load().fluxhip_silu_bf16(_p(x), _p(out), x.numel(), _stream()), "fluxhip_silu_bf16")
+    return out
+
+
 def euler_step(x: torch.Tensor, pred: torch.Tensor, dt: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _bf16c(x, "x"); _bf16c(pred, "pred")
     if out is None:

@@ -127,6 +127,12 @@ def small_linear_any(x, w, b, silu_in=False, out=None, accum=False):
     return out
 
 
+class _TembAct:
+    """silu(time embedding) of one forward, shared by every ResnetBlock2D."""
+    def __init__(self, temb: torch.Tensor):
+        self.act = ops.silu(temb)
+
+
 class UNetModel:
     def __init__(self, config: UNetConfig, device: Union[str, torch.device] = "cuda"):
         self.config = config
@@ -221,7 +227,13 @@ class UNetModel:
     def _resnet(self, p: str, x: torch.Tensor, temb: torch.Tensor) -> torch.Tensor:
         """ResnetBlock2D.__call__ (unet.py:152-170)."""
         W, G = self._params, self.config.norm_num_groups
-        tproj = small_linear_any(temb, W[f"{p}.time_emb_proj.weight"], W[f"{p}.time_emb_proj.bias"], silu_in=True)
+        # time_emb_proj(silu(temb)) (unet.py:158-159).  At batch > 4 the 22 projections go through the MFMA GEMM on silu(temb)
+        # computed ONCE per forward (_TembAct): the GEMV kernel re-evaluates the silu per output-row pair and spends 16 FMAs per
+        # weight element - 50 us per resnet at batch 16 against ~10 for the GEMM
+        if isinstance(temb, _TembAct):
+            tproj = ops.linear(temb.act, W[f"{p}.time_emb_proj.weight"], W[f"{p}.time_emb_proj.bias"])
+        else:
+            tproj = small_linear_any(temb, W[f"{p}.time_emb_proj.weight"], W[f"{p}.time_emb_proj.bias"], silu_in=True)
         h = ops.groupnorm_silu(x, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], G, 1e-5, True)
         h = ops.conv2d(h, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"], addvec=tproj)
         h = ops.groupnorm_silu(h, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], G, 1e-5, True)
@@ -354,6 +366,8 @@ class UNetModel:
             h1 = small_linear_any(e, W["add_embedding.linear_1.weight"], W["add_embedding.linear_1.bias"])
             small_linear_any(h1, W["add_embedding.linear_2.weight"], W["add_embedding.linear_2.bias"], silu_in=True,
                              out=temb, accum=True)
+        if B > 4 and os.environ.get("FLUXHIP_UNET_TEMB") != "gemv":      # ("gemv": A/B timing)
+            temb = _TembAct(temb)
         # the cross-attention K / V^T of every layer: given by the caller (once per job) or projected here
         S = encoder_x.shape[1]
         mem = text_kv if text_kv is not None else self.text_kv(self.pad_encoder_states(encoder_x))
