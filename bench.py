@@ -201,11 +201,8 @@ def main() -> None:
     # broadcast / barrier / max-reduce / gather code an 8-GPU launch runs
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
-    if share_gpu:
-        # two processes on ONE GPU: the reduce-scatter split-K hand-off assumes its whole grid is resident (one process per GPU);
-        # with a second process holding CUs, two such launches can wait for each other's unscheduled peers until the kernel's
-        # bounded spin traps.  The chain hand-off only ever waits for a block that is already running.
-        os.environ["FLUXHIP_SPLITK"] = "chain"
+    # (two processes on ONE GPU need no special mode: the reduce-scatter split-K hand-off completes without co-residency,
+    # include/fluxhip.h fluxhip_gemm_set_splitk_mode)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -64,6 +64,7 @@ SIGNATURES = {
     "fluxhip_gemm_set_splitk_mode": (c_int, [c_int]),
     "fluxhip_attention_set_variant": (c_int, [c_int]),
     "fluxhip_gemm_rs_launches": (C.c_int64, []),
+    "fluxhip_gemm_set_rs_timeout_us": (c_int, [c_int]),
     "fluxhip_gemm_set_lean": (c_int, [c_int]),
     "fluxhip_gemm_lean_launches": (C.c_int64, []),
     "fluxhip_set_workspace": (c_int, [c_void_p, c_int64]),

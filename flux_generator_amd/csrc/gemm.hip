@@ -253,7 +253,38 @@ constexpr float kRsHopUs = 9.0f, kRsHopNextUs = 4.0f; // reduce-scatter hand-off
 int g_num_cus = 0;                                    // CUs of the bound device (reduce-scatter needs the whole grid resident)
 // FLUXHIP_SPLITK=chain (or fluxhip_gemm_set_splitk_mode(1)) keeps every split-K launch on the chain (A/B runs, diagnostics)
 bool g_rs_enabled = [] { const char* e = getenv("FLUXHIP_SPLITK"); return !(e && e[0] == 'c'); }();
+bool g_rs_any_grid = false;      // fluxhip_gemm_set_splitk_mode(2), tests: reduce-scatter also for grids larger than the chip
 long long g_rs_launches = 0;
+// how long a block of a reduce-scatter tile polls for its peers before it orphans its slice and exits (gemm_core.h, hand-off):
+// 100 MHz ticks.  100 us is 10-20x the skew between the blocks of a resident grid; a false timeout only costs time (the
+// wait-free completion gives the same bits).  FLUXHIP_RS_TIMEOUT_US / fluxhip_gemm_set_rs_timeout_us override (tests use 0
+// to force every early block through the orphan path).
+int g_rs_timeout_ticks = [] { const char* e = getenv("FLUXHIP_RS_TIMEOUT_US"); return (e && *e) ? atoi(e) * 100 : 10000; }();
+// The split-K workspace (counters + partial slabs) belongs to ONE launch at a time.  Launches on one stream are ordered by
+// the stream; when the stream changes, the new one is made to wait for everything the previous one has enqueued so far.
+hipStream_t g_ws_stream = nullptr;
+bool g_ws_stream_set = false;
+hipEvent_t g_ws_event = nullptr;
+
+int serialize_workspace_user(hipStream_t s) {
+  if (g_ws_stream_set && g_ws_stream == s) return FLUXHIP_OK;
+  if (g_ws_stream_set) {
+    hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(g_ws_stream, &a);
+    (void)hipStreamIsCapturing(s, &b);
+    (void)hipGetLastError();
+    // a capturing stream cannot be joined from outside the capture (and a graph is ordered by the stream that replays it)
+    if (a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone) {
+      if (!g_ws_event && hipEventCreateWithFlags(&g_ws_event, hipEventDisableTiming) != hipSuccess) return FLUXHIP_ELAUNCH;
+      if (hipEventRecord(g_ws_event, g_ws_stream) != hipSuccess || hipStreamWaitEvent(s, g_ws_event, 0) != hipSuccess) {
+        (void)hipGetLastError();      // the previous stream was destroyed: whatever it ran has been synchronised by its owner
+      }
+    }
+  }
+  g_ws_stream = s;
+  g_ws_stream_set = true;
+  return FLUXHIP_OK;
+}
 // FLUXHIP_LEAN=0 (or fluxhip_gemm_set_lean(0)): every launch on the generic kernels (A/B runs, tests)
 bool g_lean_enabled = [] { const char* e = getenv("FLUXHIP_LEAN"); return !(e && e[0] == '0'); }();
 long long g_lean_launches = 0;
@@ -271,7 +302,8 @@ bool rs_ok(int cfg, int S, long long tiles, bool conv, bool x3, bool f8) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
     g_num_cus = pr.multiProcessorCount;
   }
-  if (tiles * S > g_num_cus || tiles > kSkMaxTiles / 2) return false;
+  // (performance, not safety: a grid that is not resident as a whole completes through the orphan path of the hand-off)
+  if ((tiles * S > g_num_cus && !g_rs_any_grid) || tiles > kSkMaxTiles / 2) return false;
   return kSkFlagBytes + tiles * S * t.bm * t.bn * 4LL <= g_ws_bytes;
 }
 
@@ -398,6 +430,8 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     p.sk_part = (float*)(g_ws + kSkFlagBytes);
     p.sk_mode = (lean_ok && p.epi == c.rs_epi && rs_ok(cfg_idx, splits, tiles, conv, x3, f8)) ? 1 : 0;   // (the reduce-scatter kernels are lean: LDS-transposed epilogue, transformer-block epilogues)
     p.sk_depart = p.sk_flag + kSkMaxTiles / 2;
+    p.sk_timeout = g_rs_timeout_ticks;
+    if (serialize_workspace_user(s) != FLUXHIP_OK) return FLUXHIP_ELAUNCH;
     g_rs_launches += p.sk_mode != 0;
     if (p.sk_mode && !use(c.dense_rs, 5)) return FLUXHIP_ELAUNCH;
   }
@@ -558,12 +592,19 @@ extern "C" int fluxhip_set_workspace(void* ws, int64_t bytes) {
 }
 
 extern "C" int fluxhip_gemm_set_splitk_mode(int mode) {
-  if (mode != 0 && mode != 1) return FLUXHIP_EINVAL;
-  g_rs_enabled = mode == 0;
+  if (mode < 0 || mode > 2) return FLUXHIP_EINVAL;
+  g_rs_enabled = mode != 1;
+  g_rs_any_grid = mode == 2;
   return FLUXHIP_OK;
 }
 
 extern "C" int64_t fluxhip_gemm_rs_launches(void) { return g_rs_launches; }
+
+extern "C" int fluxhip_gemm_set_rs_timeout_us(int us) {
+  if (us < 0 || us > 10000000) return FLUXHIP_EINVAL;
+  g_rs_timeout_ticks = us * 100;
+  return FLUXHIP_OK;
+}
 
 extern "C" int fluxhip_gemm_set_lean(int on) {
   g_lean_enabled = on != 0;

@@ -98,6 +98,7 @@ struct GemmParams {
   int sk_mode;           // 0: chain (block s adds the partial of block s-1);  1: reduce-scatter (ping-pong tiles only, every
                          //    split block resident at once: grid <= CUs) — see the split-K note at the hand-off
   int* sk_depart;        // sk_mode 1: [tiles] departure counters (zero between launches; the last block to leave resets both)
+  int sk_timeout;        // sk_mode 1: how long (100 MHz ticks) a block polls for its peers before it orphans its slice and exits
   int wide_epi;          // outputs / residual / gate are 16-byte addressable: LDS-transposed epilogue
   unsigned long long* trace;  // FLAG_TIMED kernels only: [nblk][nwaves][8] summed segment cycles
   // FLAG_SPLIT kernels only ("bf16x3": fp32-faithful products on the bf16 matrix cores).  Every operand is a pair
@@ -997,11 +998,22 @@ void gemm_nt_kernel(const GemmParams p) {
   // counter, one lane polls it (relaxed) until all S have arrived, ONE agent acquire drops this CU's stale L1 lines, and the
   // block adds its peers' partials of the fragments it owns (fixed peer order: deterministic) and runs the epilogue on
   // them only.  All S hand-offs are concurrent; bytes per block: (S-1)/S of a tile out, the same in.  Placement
-  // independent (cdna guide, Guideline 16 R1); the blocks wait for EACH OTHER, so the launcher only selects this mode when
-  // the whole grid is resident (one block per CU, grid <= CUs).  The last block to leave a tile zeroes both counters.
+  // independent (cdna guide, Guideline 16 R1).  The last block to leave a tile zeroes both counters.
+  // The blocks of a tile wait for EACH OTHER, which is only live when all of them are resident.  The launcher selects the
+  // mode when grid <= CUs, but residency is not its to guarantee (a second process on the GPU, masked CUs, a partition
+  // mode), so the wait is BOUNDED and the protocol has a wait-free completion: the tile's counter word carries the
+  // arrivals in bits 0-7 and an ORPHAN mask above.  A block whose peers have not all arrived after p.sk_timeout publishes
+  // the partial of its OWN slice as well (the slab has the slot), sets its orphan bit with the same kind of atomic and
+  // EXITS, freeing its CU.  The block whose arrival completes the count is the one party that never waits: it finishes
+  // its own slice and then every slice whose orphan bit was set BEFORE its arrival (the atomic's return value) from the
+  // slab — same summation order (owner's partial first, then the peers by index), same bf16 epilogue arithmetic, so the
+  // result is bit-identical whichever path a slice took.  An orphan bit set AFTER the last arrival is seen by its own
+  // setter (count == S in the value its atomic returns), who then simply continues on the fast path.  Nobody waits
+  // unboundedly, nobody depends on co-residency.
   constexpr bool RS_CAPABLE = (FLAGS & FLAG_RS) != 0;
   static_assert(!RS_CAPABLE || (PP && !X3 && !F8 && AMODE == 0), "reduce-scatter split-K: ping-pong dense bf16 tiles");
   bool rs = false;
+  int rs_orphans = 0;                                   // last arriver only: slices whose owners gave up waiting (bit s)
   if constexpr (RS_CAPABLE) {
     if (LEAN || (S > 1 && p.sk_mode != 0)) {
       rs = true;
@@ -1030,18 +1042,56 @@ void gemm_nt_kernel(const GemmParams p) {
       if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_rs1)::"memory");
       __syncthreads();
       int* arrive = p.sk_flag + bid;
+      int* const bcast = (int*)smem;                  // the operand ring is dead (block barrier above)
       if (tid == 0) {
-        __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // bounded spin: the peers are resident by construction (grid <= CUs); if that ever fails to hold — CUs masked away from
-        // this process, a device partition mode — the launch dies loudly (trap) after ~1 s instead of hanging the queue
-        unsigned spins = 0;
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 24)) __builtin_trap();
+        const int old = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int gave_up = 0, orphans = 0;
+        if ((old & 255) + 1 == S) {
+          orphans = old >> 8;                           // last arriver: never waits, finishes what was orphaned before it came
+        } else {
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          while ((__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 255) < S) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 >= (unsigned long long)p.sk_timeout) { gave_up = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+          }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv: this CU's L1 may hold last launch's slab lines
+        bcast[0] = gave_up;
+        bcast[1] = orphans;
+        if (!gave_up) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv: this CU's L1 may hold last launch's slab lines
       }
       __syncthreads();
+      int gave_up = __builtin_amdgcn_readfirstlane(bcast[0]);
+      rs_orphans = __builtin_amdgcn_readfirstlane(bcast[1]);
+      if (gave_up) {                                    // rare: peers not resident (shared / partitioned GPU)
+        __syncthreads();                                // everybody has read the broadcast words
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if (i < oi_lo || i >= oi_hi || j < oj_lo || j >= oj_hi) continue;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrc, my_off + (i * NJ + j) * 1024, 0, 16);
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          const int old2 = __hip_atomic_fetch_add(arrive, 1 << (8 + sidx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int still = (old2 & 255) < S;           // the last arriver is yet to come and will see the bit
+          bcast[0] = still;
+          if (!still) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        gave_up = __builtin_amdgcn_readfirstlane(bcast[0]);
+        if (gave_up) {
+          if (tid == 0) {
+            const int left = __hip_atomic_fetch_add(p.sk_depart + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (left == S - 1) {
+              __hip_atomic_store(p.sk_depart + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          return;
+        }
+      }
       if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_rs2)::"memory");
       const f32x4* rd = (const f32x4*)slab + (size_t)wave * F * 64 + lane;
       for (int s2 = 0; s2 < S; ++s2) {                       // peers in index order (skipping myself): fixed summation order
@@ -1407,6 +1457,44 @@ void gemm_nt_kernel(const GemmParams p) {
         o[0] = pack_bf16x2(v[0], v[1]);
         o[1] = pack_bf16x2(v[2], v[3]);
         *(u32x2*)dst = o;
+      }
+    }
+  }
+  // ---- reduce-scatter split-K, wait-free completion: the last arriver of a tile finishes the slices whose owners gave up
+  // waiting (see the hand-off).  Rare path: direct stores from the MFMA layout; the arithmetic is that of the LDS-transposed
+  // epilogue (bf16-rounded acc * alpha + bias, then the fused form), the summation order that of the owner.
+  if constexpr (RS_CAPABLE) {
+    if (rs_orphans != 0) {
+      constexpr int F = MI * NJ;
+      const bool by_rows = (MI % S) == 0;
+      const f32x4* rd = (const f32x4*)(p.sk_part + (size_t)bid * ((size_t)S * BM * BN)) + (size_t)wave * F * 64 + lane;
+      for (int so = 0; so < S; ++so) {
+        if (((rs_orphans >> so) & 1) == 0) continue;
+        int ai_lo = 0, ai_hi = MI, aj_lo = 0, aj_hi = NJ;
+        if (by_rows) { ai_lo = so * (MI / S); ai_hi = ai_lo + MI / S; }
+        else { aj_lo = so * (NJ / S); aj_hi = aj_lo + NJ / S; }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if (i < ai_lo || i >= ai_hi || j < aj_lo || j >= aj_hi) continue;      // wave-uniform
+            f32x4 sum = __builtin_nontemporal_load(rd + (size_t)so * NWAVES * F * 64 + (i * NJ + j) * 64);
+            for (int s2 = 0; s2 < S; ++s2)
+              if (s2 != so) sum += __builtin_nontemporal_load(rd + (size_t)s2 * NWAVES * F * 64 + (i * NJ + j) * 64);
+            acc[i][j] = sum;
+            const int m = m0 + wm * WTM + i * 16 + r16, n4 = n0 + wn * WTN + j * 16 + q4 * 4;
+            if (m >= Mg || n4 >= N) continue;
+            float v[4];
+            biased(std::false_type{}, i, j, m, n4, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+            bf16_t* dst;
+            finish(v, 4, m, n4, dst);
+            u32x2 o;
+            o[0] = pack_bf16x2(v[0], v[1]);
+            o[1] = pack_bf16x2(v[2], v[3]);
+            *(u32x2*)dst = o;
+          }
       }
     }
   }

@@ -97,9 +97,19 @@ int fluxhip_set_workspace(void* ws, int64_t bytes);
  * split grid is resident at once (tiles x splits <= CUs): the S blocks of a tile exchange write-through partials
  * concurrently and each finishes 1/S of the tile; everything else uses the chain (block s adds the partial of block s-1).
  * 1: chain only (diagnostics, A/B timing).  Both are deterministic; they differ in fp32 summation order.
- * fluxhip_gemm_rs_launches: number of reduce-scatter launches issued so far by this process (tests, profiling). */
+ * 2 (tests): like 0 without the "grid <= CUs" condition - exercises the hand-off's completion path for blocks that are
+ * not co-resident on an exclusive GPU.
+ * fluxhip_gemm_rs_launches: number of reduce-scatter launches issued so far by this process (tests, profiling).
+ * Neither mode depends on the grid being co-resident: the chain only waits for lower block ids, and a reduce-scatter block
+ * polls for its peers for at most fluxhip_gemm_set_rs_timeout_us (default 100 us; env FLUXHIP_RS_TIMEOUT_US), then
+ * publishes its slice, exits, and the tile's last arriver finishes it from the workspace - bit-identical either way, so a
+ * GPU shared with other processes (or with CUs masked) is slower, never wrong and never stuck.
+ * The split-K workspace serves one launch at a time: launches on one stream are ordered by it, and when the launching
+ * stream changes the library makes the new stream wait for the work enqueued on the previous one (outside stream capture;
+ * a captured graph must be replayed on a stream ordered with other split-K users by the caller). */
 int fluxhip_gemm_set_splitk_mode(int mode);
 int64_t fluxhip_gemm_rs_launches(void);
+int fluxhip_gemm_set_rs_timeout_us(int us);
 /* Lean kernels.  The tiles the transformer-block launches run on also exist as instantiations with ONE epilogue compiled
  * in (bias; bias + GELU-tanh; gate-residual; split-GELU) on the LDS-transposed store path and nothing else - no other
  * activation, no row bias / addvec / float32 output, no split-K chain; a launch that fits one takes it (same arithmetic,

@@ -578,3 +578,35 @@ def test_two_ranks_share_one_gpu_end_to_end(dev, tmp_path):
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
     assert res[0]["ok"] and res[1]["ok"], res
     assert res[0]["shard"] == (0, 3) and res[1]["shard"] == (3, 5)
+
+
+def test_two_default_mode_processes_share_one_gpu(dev, tmp_path):
+    """Two independent processes run 20 full-size Flux-schnell forwards each (C2 shape) on this GPU AT THE SAME TIME with the
+    library's default split-K hand-off (reduce-scatter: 57 launches per forward whose S blocks per tile wait for each
+    other).  Neither process owns the GPU, so neither grid is resident as a whole — what used to deadlock and trap.  Both
+    must finish without a fault and produce the bits of a process that had the GPU to itself (the orphan completion of the
+    hand-off is bit-identical to its fast path).  tests/shared_gpu_worker.py."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shared_gpu_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("FLUXHIP_SPLITK", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    torch.cuda.empty_cache()
+
+    def launch(tag, sync, n):
+        os.makedirs(sync, exist_ok=True)
+        return subprocess.Popen([sys.executable, worker, tag, "20", str(sync), str(n), str(tmp_path / f"{tag}.pt")], env=env,
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+    solo = launch("solo", tmp_path / "s1", 1)
+    out = solo.communicate(timeout=900)[0]
+    assert solo.returncode == 0, out[-2000:]
+    procs = [launch(f"p{i}", tmp_path / "s2", 2) for i in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    ref = torch.load(tmp_path / "solo.pt")
+    assert ref["finite"] and ref["rs_launches"] == 20 * 57
+    for i in range(2):
+        r = torch.load(tmp_path / f"p{i}.pt")
+        assert r["rs_launches"] == 20 * 57, "the shared processes did not run the reduce-scatter hand-off"
+        assert torch.equal(r["first"], ref["first"]) and torch.equal(r["last"], ref["last"]), f"process {i}"
+        print(f"shared-GPU process {i}: {r['seconds']:.2f} s for 20 forwards (alone: {ref['seconds']:.2f} s)")

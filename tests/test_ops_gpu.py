@@ -256,6 +256,83 @@ def test_gemm_split_k_reduce_scatter_under_uneven_load(dev):
         assert torch.equal(y, first[it & 1]), f"iteration {it}"
 
 
+@pytest.mark.parametrize("cfg,S", [(49, 2), (49, 4), (51, 3), (51, 4), (56, 3)])
+def test_gemm_split_k_reduce_scatter_orphan_path_same_bits(dev, cfg, S):
+    """The wait-free completion of the reduce-scatter hand-off (a block whose peers have not arrived in time publishes its own
+    slice, sets its orphan bit and exits; the tile's last arriver finishes the orphaned slices from the workspace).  With a
+    poll time of 0 every block that is not already complete on arrival takes that path; the results must be the SAME BITS as
+    with the default poll time (same summation order, same epilogue arithmetic), launch after launch, and the counters must be
+    left clean for the next launch (ragged M / N edges, gate-residual epilogue, both ownership layouts)."""
+    from flux_generator_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = 600, 520, 2048
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    res, gate = rnd(M, N, seed=4), rnd(N, seed=5)
+    code = cfg | (S << 8)
+    run = lambda: ops.linear(x, w, b, epi=ops.EPI_GATE_RES, res=res, gate=gate, tile_cfg=code)      # noqa: E731
+    want = run().clone()
+    lin = O.linear(x.float().cpu(), w.float().cpu(), b.float().cpu())
+    assert rel_l2(want, res.float().cpu() + gate.float().cpu() * lin) < TOL
+    assert lib.fluxhip_gemm_set_rs_timeout_us(0) == 0
+    try:
+        n0 = _rs_launches()
+        for it in range(6):
+            assert torch.equal(run(), want), f"orphan path, launch {it}"
+        assert _rs_launches() == n0 + 6
+    finally:
+        assert lib.fluxhip_gemm_set_rs_timeout_us(100) == 0
+    assert torch.equal(run(), want)                       # ... and back on the fast path with clean counters
+
+
+@pytest.mark.parametrize("timeout_us", [100, 0, 5])
+def test_gemm_split_k_reduce_scatter_grid_larger_than_the_chip(dev, timeout_us):
+    """The situation that used to be fatal (a process sharing its GPU, masked CUs): the blocks of a tile are NOT all resident.
+    Forced here on an exclusive GPU with a 480-block reduce-scatter grid on 256 CUs (mode 2 lifts the launcher's grid <= CUs
+    condition): in XCD-brick order the first 256 blocks are all first / second splits and wait for third splits that cannot
+    start before somebody leaves.  The bounded poll + orphan hand-off must complete, give the bits of the resident case for
+    every tile (same problem solved as two resident halves), and repeat."""
+    from flux_generator_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = 2560, 3072, 3072
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    res, gate = rnd(M, N, seed=4), rnd(N, seed=5)
+    code = 51 | (3 << 8)                                   # 256 x 192 tiles: 10 x 16 tiles x 3 splits = 480 blocks
+    halves = [ops.linear(x[i * 1280:(i + 1) * 1280], w, b, epi=ops.EPI_GATE_RES, res=res[i * 1280:(i + 1) * 1280], gate=gate,
+                         tile_cfg=code) for i in range(2)]       # 240 blocks each: resident, fast path
+    want = torch.cat(halves, dim=0)
+    assert lib.fluxhip_gemm_set_splitk_mode(2) == 0 and lib.fluxhip_gemm_set_rs_timeout_us(timeout_us) == 0
+    try:
+        n0 = _rs_launches()
+        for it in range(4):
+            y = ops.linear(x, w, b, epi=ops.EPI_GATE_RES, res=res, gate=gate, tile_cfg=code)
+            torch.cuda.synchronize()
+            assert torch.equal(y, want), f"launch {it}"
+        assert _rs_launches() == n0 + 4, "the launch did not take the reduce-scatter kernel"
+    finally:
+        assert lib.fluxhip_gemm_set_splitk_mode(0) == 0 and lib.fluxhip_gemm_set_rs_timeout_us(100) == 0
+
+
+def test_gemm_split_k_workspace_is_serialised_across_streams(dev):
+    """The split-K workspace serves one launch at a time: when the launching stream changes, the library orders the new
+    stream after the work already enqueued on the previous one (two reduce-scatter launches issued back to back on two
+    streams without any caller-side dependency must both be right)."""
+    from flux_generator_amd import ops
+    M, N, K = 1280, 3072, 12288
+    xs = [rnd(M, K, seed=s) for s in (1, 2)]
+    w = rnd(N, K, seed=3, scale=K ** -0.5)
+    res = rnd(M, N, seed=4)
+    want = [ops.linear(x, w, None, epi=ops.EPI_GATE_RES, res=res).clone() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for it in range(8):
+        outs = []
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs.append(ops.linear(xs[i], w, None, epi=ops.EPI_GATE_RES, res=res))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], want[0]) and torch.equal(outs[1], want[1]), f"iteration {it}"
+
+
 def test_gemm_split_k_reduce_scatter_grouped_batched(dev):
     """Reduce-scatter split-K under the 2-group (txt / img), batched launch shape of the double blocks' mlp2 with per-batch
     gates, forced onto 256 x 256 tiles with S = 4 (ownership by fragment rows)."""
