@@ -69,21 +69,40 @@ def cpu_baseline_sample(T: int, threads: int, S: int = 256) -> dict:
         for _ in range(NS):
             x = O.single_stream_block(W, "single_blocks.0", 24, x, vec, pe)
         t_single = (time.perf_counter() - t0) / NS
-    per_image = 2 * (19 * t_double + 38 * t_single)
-    return {"value": 1.0 / per_image, "unit": "images/sec (transformer only: VAE decode not timed)", "cores": threads, "kind": "port",
+    # the VAE decode of the same image (64 x 64 x 16 latents -> 512 x 512 x 3) in the reference's float32, once
+    A = O.AutoEncoderParams()
+    WA = O.init_weights(O.decoder_weight_shapes(A), seed=1)
+    lat = int(round(((T - S) * 4) ** 0.5))
+    z = torch.randn(1, (lat // 2) ** 2, 64, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.pipeline_decode(A, WA, z, (lat, lat))
+        t_vae = time.perf_counter() - t0
+    per_image = 2 * (19 * t_double + 38 * t_single) + t_vae
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": threads, "kind": "port",
+            "blocks_timed": ND + NS, "blocks_total": 2 * (19 + 38), "vae_decode_s": t_vae,
             "sample": f"oracle fp32: {ND} x DoubleStreamBlock ({t_double:.2f} s each) + {NS} x SingleStreamBlock ({t_single:.2f} s each) "
-                      f"at full width, T={T}, after one warm-up block; extrapolated to 2 steps x (19+38) blocks, VAE decode excluded"}
+                      f"at full width, T={T}, after one warm-up block, extrapolated to 2 steps x (19+38) blocks; + ONE float32 VAE decode "
+                      f"of the {lat}x{lat} latents ({t_vae:.1f} s, timed whole, cold)"}
 
 
-def pmc_traffic(label: str) -> dict:
+def pmc_traffic(label: str, workload: str) -> dict:
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    (tools/profile_round.sh -> tools/pmc_summary.py; counters cannot be read from inside this process).
-    null when the summary has no row for this kernel."""
-    import csv, re
-    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic_pmc.csv")
+    (tools/profile_round*.sh -> tools/pmc_summary.py; counters cannot be read from inside this process).  The newest
+    profiles/rNN_hbm_traffic_pmc.csv is used, and only when it was collected on THIS workload (its `# workload:` header; files
+    without one were taken on the headline, "flux-schnell B1 T1280"): a launch at another M moves other bytes, so any other
+    workload reports null, as does a summary without a row for this kernel."""
+    import csv, glob, re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic_pmc.csv")))
     m = re.search(r"cfg(\d+)", label)
-    if not m or "fp8" in label or not os.path.exists(path):
+    if not m or "fp8" in label or not files:
         return {"traffic": None}
+    path = files[-1]
+    with open(path) as f:
+        head = [l for l in f if l.startswith("#")]
+    taken_on = next((l.split(":", 1)[1].strip() for l in head if l.startswith("# workload:")), "flux-schnell B1 T1280")
+    if taken_on != workload:
+        return {"traffic": None, "traffic_note": f"{os.path.basename(path)} was collected on '{taken_on}', this run is '{workload}'"}
     import ctypes
     from flux_generator_amd import _lib
     bm, bn, th = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -99,7 +118,95 @@ def pmc_traffic(label: str) -> dict:
     if best is None:
         return {"traffic": None}
     return {"traffic": float(best["avg_total_MB"]) * 1e6, "traffic_unit": "HBM+MALL bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-            "traffic_source": f"profiles/r03_hbm_traffic_pmc.csv: {best['kernel']}"}
+            "traffic_source": f"profiles/{os.path.basename(path)}: {best['kernel']}"}
+
+
+def time_other_configs(pipe, dev, reps: int = 3) -> list:
+    """One driver-timed line per remaining BASELINE.json config, measured inside the headline run (N = 1, rank 0), after
+    the headline's own measurements: C5's per-GPU shape (Flux-schnell fp8 blocks, 1024x1024, batch 4), C3 (Flux-dev
+    1024x1024, batch 1, S = 512, guidance 7) and C4 (sdxl-turbo 512x512, 1 step, batch 16).  Each entry: one denoise step
+    (graph replay, HIP events, `reps` replays) and one VAE decode of that batch, the algorithmic TFLOP/s of the step and its
+    fraction of the dense MFMA peak of the dtype.  `value` of the JSON line stays the headline (C2)."""
+    import warnings
+    from flux_generator_amd.flux.flux import FluxPipeline
+    out = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn):
+        fn()                                         # capture / warm outside the timed region
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, r
+
+    def flux_line(p, tag, B, lat, S, guidance, nsteps, dtype, peak):
+        L = (lat // 2) ** 2
+        g = torch.Generator(device=dev).manual_seed(99)
+        x_T = torch.randn(B, lat, lat, 16, generator=g, device=dev).to(torch.bfloat16)
+        txt = (torch.randn(B, S, 4096, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+        vec = torch.randn(B, 768, generator=g, device=dev).to(torch.bfloat16)
+        txt_ids = torch.zeros(B, S, 3, dtype=torch.int32, device=dev)
+        x, x_ids = p._prepare_latent_images(x_T)
+        tv = torch.full((B,), 1.0, dtype=torch.bfloat16, device=dev)
+        gv = torch.full((B,), guidance, dtype=torch.bfloat16, device=dev)
+
+        def step():
+            pred = p._flow_step(x, x_ids, txt, txt_ids, vec, tv, gv)
+            return p.sampler.step(pred, x, 1.0, 0.5)
+
+        step_ms, x1 = timed(step)
+        dec_ms, img = timed(lambda: p.decode(x1, (lat, lat)))
+        tfl = B * flux_forward_flops(L, S) / 1e12
+        ok = bool(torch.isfinite(img).all())
+        out.append({"workload": tag, "dtype": dtype, "batch": B, "denoise_step_ms": step_ms, "vae_decode_ms": dec_ms,
+                    "ms": nsteps * step_ms + dec_ms, "images_per_sec": B / ((nsteps * step_ms + dec_ms) * 1e-3),
+                    "denoise_steps_per_image": nsteps, "tflop_per_step": tfl, "tflops": tfl / (step_ms * 1e-3),
+                    "frac": tfl / (step_ms * 1e-3) / peak, "peak": peak, "finite": ok, "replays": reps,
+                    "note": "step = graph replay of one forward incl. its modulation GEMV + Euler; ms = steps x step + decode "
+                            "(fp32-faithful VAE)"})
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # C5 per-GPU shape on the weights already resident
+        pipe.flow.enable_fp8(True)
+        flux_line(pipe, "C5 per-GPU shape: Flux-schnell fp8 blocks, 1024x1024 4-step, batch 4", 4, 128, 256, 4.0, 4,
+                  "fp8 e4m3 block Linears (bf16 elsewhere)", MFMA_FP8_PEAK_TFLOPS)
+        pipe.flow.enable_fp8(False)
+        pipe._graphs.clear()
+        pipe.flow._ws.clear()
+        torch.cuda.empty_cache()
+        # C3
+        dev_pipe = FluxPipeline("flux-dev", device=str(dev))
+        flux_line(dev_pipe, "C3: Flux-dev 1024x1024 28-step, guidance 7, S = 512, batch 1 (ONE step + decode timed)", 1, 128, 512,
+                  7.0, 28, "bf16", MFMA_BF16_PEAK_TFLOPS)
+        del dev_pipe
+        torch.cuda.empty_cache()
+        # C4
+        from flux_generator_amd.stable_diffusion import StableDiffusionXL
+        sd = StableDiffusionXL("stabilityai/sdxl-turbo", float16=True)
+        B = 16
+        g = torch.Generator(device=dev).manual_seed(0)
+        x_T = sd.sampler.sample_prior((B, 64, 64, 4), key=g, device=dev)
+        cond = torch.randn(B, 77, 2048, generator=g, device=dev).to(sd.dtype)
+        pooled = torch.randn(B, 1280, generator=g, device=dev).to(sd.dtype)
+        tt = (pooled, torch.tensor([[512, 512, 0, 0, 512, 512.0]] * B, device=dev))
+        (t, tp), = sd.sampler.timesteps(1)
+        step_ms, x1 = timed(lambda: sd._denoising_step(x_T, t, tp, cond, 0.0, tt))
+        dec_ms, img = timed(lambda: sd.decode(x1))
+        tfl = 1.59 * B                                # TFLOP per UNet evaluation at 64x64 latents (tools/bench_sdxl.py)
+        out.append({"workload": "C4: sdxl-turbo 512x512 1-step, batch 16 (UNet step + VAE decode)", "dtype": str(sd.dtype).replace("torch.", ""),
+                    "batch": B, "denoise_step_ms": step_ms, "vae_decode_ms": dec_ms, "ms": step_ms + dec_ms,
+                    "images_per_sec": B / ((step_ms + dec_ms) * 1e-3), "denoise_steps_per_image": 1, "tflop_per_step": tfl,
+                    "tflops": tfl / (step_ms * 1e-3), "frac": tfl / (step_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "finite": bool(torch.isfinite(img).all()), "replays": reps,
+                    "note": "UNet in the arithmetic `dtype` names (float16=True: the reference's flux_app.py setting), "
+                            "fp32-faithful VAE decode"})
+        del sd
+        torch.cuda.empty_cache()
+    return out
 
 
 def relaunch_under_torchrun(n: int) -> int:
@@ -175,6 +282,7 @@ def main() -> None:
                     "fp8 matrix cores; defaults become 1024x1024, 4 denoise steps, batch 4 per GPU")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C4 / C5 lines (`other_configs`) of the default N = 1 run")
     ap.add_argument("--profile-only", action="store_true", help="run a few steps for rocprofv3, print nothing else")
     ap.add_argument("--guidance", type=float, default=None, help="default 4.0 (7.0 for flux-dev, BASELINE.json configs[2])")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo skeleton of the N-rank job: launch, sharding, broadcast, "
@@ -352,7 +460,7 @@ def main() -> None:
     roofline = {"bound": "mfma", "kernel": dom, "launches_per_forward": n, "avg_launch_ms": ms / n,
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "algorithmic_flop_per_launch": fl / n}
-    roofline.update(pmc_traffic(dom))
+    roofline.update(pmc_traffic(dom, f"{args.model} B{B} T{L + S}"))
     breakdown = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": (round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None)}
                  for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
 
@@ -383,6 +491,12 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sample(L + S, torch.get_num_threads(), S)
+        headline = args.model == "flux-schnell" and not args.fp8 and args.image_size == 512 and B == 1
+        if world == 1 and headline and not args.no_other_configs and not args.no_graph:
+            try:
+                out["other_configs"] = time_other_configs(pipe, dev)
+            except Exception as ex:      # the headline line must survive a failure of the side measurements
+                out["other_configs"] = [{"error": f"{type(ex).__name__}: {ex}"}]
     # RCCL prints its version banner through C stdio (flushed at exit when stdout is a pipe).  Every rank flushes it
     # now, then a barrier, then rank 0 prints: the JSON line is the LAST line of the job's output.
     def flush_c_stdio():

@@ -124,6 +124,18 @@ SIGNATURES = {
     "fluxhip_pixel_linear_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                         c_float, c_void_p]),
 }
+# float16-storage twins (the stable_diffusion/ models with float16=True): same signatures as the bf16 entry points
+for _b, _f in (("fluxhip_gemm_bf16", "fluxhip_gemm_f16"), ("fluxhip_conv2d_bf16", "fluxhip_conv2d_f16"),
+               ("fluxhip_small_linear_bf16", "fluxhip_small_linear_f16"), ("fluxhip_silu_bf16", "fluxhip_silu_f16"),
+               ("fluxhip_groupnorm_silu_bf16", "fluxhip_groupnorm_silu_f16"),
+               ("fluxhip_attention_strided_bf16", "fluxhip_attention_strided_f16"),
+               ("fluxhip_attention_strided_vt_bf16", "fluxhip_attention_strided_vt_f16"),
+               ("fluxhip_attention_masked_bf16", "fluxhip_attention_masked_f16"),
+               ("fluxhip_layernorm_affine_bf16", "fluxhip_layernorm_affine_f16"),
+               ("fluxhip_axpbypcz_bf16", "fluxhip_axpbypcz_f16"), ("fluxhip_axpbypcz_dev_bf16", "fluxhip_axpbypcz_dev_f16"),
+               ("fluxhip_sincos_embed_f32", "fluxhip_sincos_embed_f32_f16"), ("fluxhip_embedding_bf16", "fluxhip_embedding_f16"),
+               ("fluxhip_pixel_linear_x3", "fluxhip_pixel_linear_x3_f16in")):
+    SIGNATURES[_f] = SIGNATURES[_b]
 
 _lib = None
 
@@ -155,7 +167,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fluxhip_abi_version() != 5 and not ab:
+    if lib.fluxhip_abi_version() != 6 and not ab:
         raise RuntimeError("libfluxhip ABI version mismatch")
     if lib.fluxhip_arch() != b"gfx950":
         raise RuntimeError("libfluxhip was not built for gfx950")

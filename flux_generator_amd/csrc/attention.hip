@@ -52,7 +52,15 @@ struct AttnParams {
 // way by fluxhip_qk_norm_rope_bf16): the 8 keys a lane feeds to one PV MFMA - (0-3, 8-11) for lanes 0-31, (4-7, 12-15)
 // for lanes 32-63 - are then ONE 16-byte chunk, i.e. one conflict-free ds_read_b128 per fragment instead of two
 // ds_read_b64 (whose 8-byte accesses were 2-way bank conflicted: 30 % of the kernel's LDS cycles in the round-1 PMC).
-template <int HD, int NW, int MODE, int KS = 1, int VP = 0>
+template <bool H>
+DEVINL f32x16 mfma32(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  if constexpr (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// F16: the 16-bit storage type is IEEE float16 (stable_diffusion/ with float16=True) instead of bfloat16: the S and PV products
+// run on v_mfma_f32_32x32x16_f16, P is rounded to float16 (<= 256 under the lazy rescale, far inside its range)
+template <int HD, int NW, int MODE, int KS = 1, int VP = 0, bool F16 = false>
 __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(const AttnParams p) {
   constexpr int RB = HD * 2;                  // bytes per K row
   constexpr int CPR = RB / 16;                // 16-B chunks per K row
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
       __builtin_amdgcn_sched_barrier(0);            // (MFMAs have no memory operands: keep them behind the wait)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
-        sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds][kb], qf[ds], sT[kb], 0, 0, 0);
+        sT[kb] = mfma32<F16>(kf[ds][kb], qf[ds], sT[kb]);
       // next stage's K / V^T pieces, one per d-step: issued back to back after the barrier they cost every
       // wave ~1000 cycles per stage in the address path with the MFMA pipe idle
       __builtin_amdgcn_sched_barrier(0);
@@ -240,11 +248,11 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
           float b4[4] = {0.f, 0.f, 0.f, 0.f};
           if (key + 3 < Tk) {
             u32x2 bw = *(const u32x2*)(bias_q + key);
-            b4[0] = bf_lo(bw[0]); b4[1] = bf_hi(bw[0]); b4[2] = bf_lo(bw[1]); b4[3] = bf_hi(bw[1]);
+            b4[0] = e_lo<F16>(bw[0]); b4[1] = e_hi<F16>(bw[0]); b4[2] = e_lo<F16>(bw[1]); b4[3] = e_hi<F16>(bw[1]);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (key + e < Tk) b4[e] = bf2f(bias_q[key + e]);
+              if (key + e < Tk) b4[e] = e2f<F16>(bias_q[key + e]);
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) sT[kb][rg * 4 + e] = fmaf(sT[kb][rg * 4 + e], p.scale, b4[e]);
@@ -308,10 +316,10 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
         union { bf16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          pf.u[e] = pack_bf16x2(sT[kb][8 * j + 2 * e], sT[kb][8 * j + 2 * e + 1]);
+          pf.u[e] = e_pack<F16>(sT[kb][8 * j + 2 * e], sT[kb][8 * j + 2 * e + 1]);
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
-          oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j][db].v, pf.v, oT[db], 0, 0, 0);
+          oT[db] = mfma32<F16>(vf[j][db].v, pf.v, oT[db]);
       }
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -362,8 +370,8 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
       for (int rg = 0; rg < 4; ++rg) {
         const int d0 = db * 32 + 8 * rg + 4 * hi;
         u32x2 o;
-        o[0] = pack_bf16x2(oT[db][rg * 4 + 0] * inv, oT[db][rg * 4 + 1] * inv);
-        o[1] = pack_bf16x2(oT[db][rg * 4 + 2] * inv, oT[db][rg * 4 + 3] * inv);
+        o[0] = e_pack<F16>(oT[db][rg * 4 + 0] * inv, oT[db][rg * 4 + 1] * inv);
+        o[1] = e_pack<F16>(oT[db][rg * 4 + 2] * inv, oT[db][rg * 4 + 3] * inv);
         *(u32x2*)(orow + d0) = o;
       }
   }
@@ -806,11 +814,11 @@ int launch_attn128_w64(AttnParams p, int B, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 
-template <int HD, int MODE, int KS = 1, int VP = 0>
+template <int HD, int MODE, int KS = 1, int VP = 0, bool F16 = false>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
   constexpr int NW = 4;
   constexpr int lds = 2 * KS * (KV * HD * 2 + HD * KV * 2);
-  auto fn = attn_kernel<HD, NW, MODE, KS, VP>;
+  auto fn = attn_kernel<HD, NW, MODE, KS, VP, F16>;
   static bool done = false;            // one flag per template instantiation
   if (!done) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -859,26 +867,46 @@ extern "C" int fluxhip_attention_set_variant(int v) {
   return FLUXHIP_OK;
 }
 
-extern "C" int fluxhip_attention_strided_vt_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
-                                                 const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
-                                                 const void* Vt, int64_t vt_bs, void* O, int ldo, int B, int H,
-                                                 int head_dim, int Tq, int Tk, int Tkpad, float scale,
-                                                 void* stream) {
-  if (!Q || !K || !Vt || !O || B < 1 || H < 1 || Tq < 1 || Tk < 1 || Tkpad % 64 || Tkpad < Tk)
+template <bool H>
+static int attention_strided_vt(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                const void* Vt, int64_t vt_bs, void* O, int ldo, int B, int Hh,
+                                int head_dim, int Tq, int Tk, int Tkpad, float scale, void* stream) {
+  if (!Q || !K || !Vt || !O || B < 1 || Hh < 1 || Tq < 1 || Tk < 1 || Tkpad % 64 || Tkpad < Tk)
     return FLUXHIP_EINVAL;
   if ((head_dim != 64 && head_dim != 128) || ldo % 4 || q_rs % 8 || k_rs % 8 || q_hs % 8 || k_hs % 8 ||
-      q_bs % 8 || k_bs % 8 || vt_bs % 8 || vt_bs < (int64_t)H * head_dim * Tkpad)
+      q_bs % 8 || k_bs % 8 || vt_bs % 8 || vt_bs < (int64_t)Hh * head_dim * Tkpad)
     return FLUXHIP_EINVAL;
+  if (H && head_dim != 64) return FLUXHIP_EINVAL;          // float16: the UNet / CLIP head size
   AttnParams p{};
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
   p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
   p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
   p.vt_bs = vt_bs;
-  p.ldo = ldo; p.H = H; p.Tq = Tq; p.Tk = Tk; p.Tkpad = Tkpad;
+  p.ldo = ldo; p.H = Hh; p.Tq = Tq; p.Tk = Tk; p.Tkpad = Tkpad;
   p.nqb = (Tq + 127) / 128;
   p.scale_log2 = scale * 1.4426950408889634f;
-  return head_dim == 128 ? launch_attn<128, 0>(p, B, (hipStream_t)stream)
-                         : launch_attn<64, 0>(p, B, (hipStream_t)stream);
+  if constexpr (H) return launch_attn<64, 0, 1, 0, true>(p, B, (hipStream_t)stream);
+  else return head_dim == 128 ? launch_attn<128, 0>(p, B, (hipStream_t)stream)
+                              : launch_attn<64, 0>(p, B, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_attention_strided_vt_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                                 const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                                 const void* Vt, int64_t vt_bs, void* O, int ldo, int B, int H,
+                                                 int head_dim, int Tq, int Tk, int Tkpad, float scale,
+                                                 void* stream) {
+  return attention_strided_vt<false>(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, Vt, vt_bs, O, ldo, B, H, head_dim, Tq, Tk,
+                                     Tkpad, scale, stream);
+}
+// float16 storage, head_dim 64 (the UNet's nn.MultiHeadAttention with float16=True)
+extern "C" int fluxhip_attention_strided_vt_f16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                                const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                                const void* Vt, int64_t vt_bs, void* O, int ldo, int B, int H,
+                                                int head_dim, int Tq, int Tk, int Tkpad, float scale,
+                                                void* stream) {
+  return attention_strided_vt<true>(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, Vt, vt_bs, O, ldo, B, H, head_dim, Tq, Tk,
+                                    Tkpad, scale, stream);
 }
 
 extern "C" int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
@@ -886,16 +914,26 @@ extern "C" int fluxhip_attention_strided_bf16(const void* Q, int64_t q_bs, int64
                                               const void* Vt, void* O, int ldo, int B, int H,
                                               int head_dim, int Tq, int Tk, int Tkpad, float scale,
                                               void* stream) {
-  return fluxhip_attention_strided_vt_bf16(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, Vt,
-                                           (int64_t)H * head_dim * Tkpad, O, ldo, B, H, head_dim, Tq, Tk, Tkpad,
-                                           scale, stream);
+  return attention_strided_vt<false>(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, Vt,
+                                     (int64_t)H * head_dim * Tkpad, O, ldo, B, H, head_dim, Tq, Tk, Tkpad,
+                                     scale, stream);
+}
+extern "C" int fluxhip_attention_strided_f16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                             const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                             const void* Vt, void* O, int ldo, int B, int H,
+                                             int head_dim, int Tq, int Tk, int Tkpad, float scale,
+                                             void* stream) {
+  return attention_strided_vt<true>(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, Vt,
+                                    (int64_t)H * head_dim * Tkpad, O, ldo, B, H, head_dim, Tq, Tk, Tkpad,
+                                    scale, stream);
 }
 
-extern "C" int fluxhip_attention_masked_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
-                                             const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
-                                             const void* Vt, void* O, int ldo, int B, int H, int Tq,
-                                             int Tk, int Tkpad, float scale, const void* bias,
-                                             int causal, void* stream) {
+template <bool F16>
+static int attention_masked(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                            const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                            const void* Vt, void* O, int ldo, int B, int H, int Tq,
+                            int Tk, int Tkpad, float scale, const void* bias,
+                            int causal, void* stream) {
   if (!Q || !K || !Vt || !O || B < 1 || H < 1 || Tq < 1 || Tk < 1 || Tkpad % 64 || Tkpad < Tk)
     return FLUXHIP_EINVAL;
   if (ldo % 4 || q_rs % 8 || k_rs % 8 || q_hs % 8 || k_hs % 8 || q_bs % 8 || k_bs % 8) return FLUXHIP_EINVAL;
@@ -911,5 +949,22 @@ extern "C" int fluxhip_attention_masked_bf16(const void* Q, int64_t q_bs, int64_
   p.scale_log2 = scale * 1.4426950408889634f;
   p.scale = scale;
   p.bias = (const bf16_t*)bias;
-  return bias ? launch_attn<64, 1>(p, B, (hipStream_t)stream) : launch_attn<64, 2>(p, B, (hipStream_t)stream);
+  if constexpr (F16) return bias ? FLUXHIP_EINVAL : launch_attn<64, 2, 1, 0, true>(p, B, (hipStream_t)stream);   // (T5's bias mode: bf16 only)
+  else return bias ? launch_attn<64, 1>(p, B, (hipStream_t)stream) : launch_attn<64, 2>(p, B, (hipStream_t)stream);
+}
+
+extern "C" int fluxhip_attention_masked_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                             const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                             const void* Vt, void* O, int ldo, int B, int H, int Tq,
+                                             int Tk, int Tkpad, float scale, const void* bias,
+                                             int causal, void* stream) {
+  return attention_masked<false>(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, Vt, O, ldo, B, H, Tq, Tk, Tkpad, scale, bias, causal, stream);
+}
+// float16 storage, causal only (the CLIP text towers of the stable_diffusion/ pipelines with float16=True)
+extern "C" int fluxhip_attention_masked_f16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                            const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                            const void* Vt, void* O, int ldo, int B, int H, int Tq,
+                                            int Tk, int Tkpad, float scale, const void* bias,
+                                            int causal, void* stream) {
+  return attention_masked<true>(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, Vt, O, ldo, B, H, Tq, Tk, Tkpad, scale, bias, causal, stream);
 }

@@ -6,7 +6,7 @@ OUT=../lib
 mkdir -p "$OUT" build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
-SRCS="api gemm gemm_conv gemm_x3f8 small_linear norm groupnorm attention elementwise unet_ops"
+SRCS="api gemm gemm_conv gemm_x3f8 gemm_f16 gemm_conv_f16 small_linear norm groupnorm attention elementwise unet_ops"
 pids=()
 for s in $SRCS; do
   if [ ! -f build/$s.o ] || [ $s.hip -nt build/$s.o ] || [ common.h -nt build/$s.o ] || \

@@ -38,6 +38,30 @@ DEVINL bf16_t f2bf(float f) {
 // value of f after a round trip through bf16 storage (MLX op-boundary rounding)
 DEVINL float rbf(float f) { return bf2f(f2bf(f)); }
 
+// ---- 16-bit storage element, selected at compile time: bfloat16 (H = false) or IEEE float16 (H = true).
+// The stable_diffusion/ path runs in float16 when the caller says float16=True (the reference's flux_app.py setting): same
+// kernels, same fp32 accumulation / norms / softmax, the element conversions and the MFMA operand type are the only difference.
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;   // MFMA A/B fragment of v_mfma_f32_16x16x32_f16 (4 VGPRs)
+DEVINL float h2f(uint16_t h) { return (float)__builtin_bit_cast(half_t, h); }
+DEVINL float h_lo(uint32_t w) { return (float)__builtin_bit_cast(half_t, (uint16_t)(w & 0xffffu)); }
+DEVINL float h_hi(uint32_t w) { return (float)__builtin_bit_cast(half_t, (uint16_t)(w >> 16)); }
+// round-to-nearest-even f32 -> f16 (values beyond 65504 become inf, as in the reference's float16 arithmetic)
+DEVINL uint32_t pack_f16x2(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  f16x2_t r = __builtin_convertvector(v, f16x2_t);
+  return __builtin_bit_cast(uint32_t, r);
+}
+DEVINL uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (half_t)f); }
+template <bool H> DEVINL float e2f(uint16_t h) { if constexpr (H) return h2f(h); else return bf2f(h); }
+template <bool H> DEVINL float e_lo(uint32_t w) { if constexpr (H) return h_lo(w); else return bf_lo(w); }
+template <bool H> DEVINL float e_hi(uint32_t w) { if constexpr (H) return h_hi(w); else return bf_hi(w); }
+template <bool H> DEVINL uint32_t e_pack(float lo, float hi) { if constexpr (H) return pack_f16x2(lo, hi); else return pack_bf16x2(lo, hi); }
+template <bool H> DEVINL uint16_t f2e(float f) { if constexpr (H) return f2h(f); else return f2bf(f); }
+// value of f after a round trip through the 16-bit storage type (op-boundary rounding of the reference's arrays)
+template <bool H> DEVINL float e_rnd(float f) { return e2f<H>(f2e<H>(f)); }
+
 DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // GELU, tanh approximation: 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
 DEVINL float gelu_tanh_f(float x) {

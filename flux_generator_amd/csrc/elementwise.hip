@@ -329,6 +329,10 @@ __global__ __launch_bounds__(256) void unpack_x3_kernel(const bf16_t* __restrict
   out[i + out_lo] = f2bf(v - bf2f(hh));
 }
 
+// XH: x is IEEE float16 (latents of a float16=True pipeline).  The reference divides by the scaling factor in the latents'
+// dtype before the float32 Linear promotes (vae.py:256-258: z / scaling_factor on a float16 array), so the quotient is rounded
+// to float16 here as well.
+template <bool XH = false>
 __global__ __launch_bounds__(256) void pixel_linear_x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                               long long out_lo, long long npix, int Cin, int Cout,
@@ -340,7 +344,10 @@ __global__ __launch_bounds__(256) void pixel_linear_x3_kernel(const bf16_t* __re
   float acc = 0.f;
   if (co < Cout) {
     acc = bias ? bias[co] : 0.f;
-    for (int c = 0; c < Cin; ++c) acc += (bf2f(x[p * Cin + c]) / in_div) * w[co * Cin + c];
+    for (int c = 0; c < Cin; ++c) {
+      const float zc = XH ? e_rnd<true>(h2f(x[p * Cin + c]) / in_div) : bf2f(x[p * Cin + c]) / in_div;
+      acc += zc * w[co * Cin + c];
+    }
   }
   const bf16_t hh = f2bf(acc);
   out[i] = hh;
@@ -624,15 +631,22 @@ extern "C" int fluxhip_rope_table_bf16(const void* ids, void* out, int64_t ntok,
 // steps' vectors (Flux.modulation_tables) the activation is taken out of the weight-streaming loop: same function,
 // same bf16 rounding, so both orders give identical bits.
 namespace {
-__global__ __launch_bounds__(256) void silu_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long n) {
+template <bool H>
+__global__ __launch_bounds__(256) void silu16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = f2bf(silu_f(bf2f(x[i])));
+  if (i < n) out[i] = f2e<H>(silu_f(e2f<H>(x[i])));
 }
 }  // namespace
 
 extern "C" int fluxhip_silu_bf16(const void* x, void* out, int64_t n, void* stream) {
   if (!x || !out || n < 1) return FLUXHIP_EINVAL;
-  hipLaunchKernelGGL(silu_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(silu16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)out, (long long)n);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+extern "C" int fluxhip_silu_f16(const void* x, void* out, int64_t n, void* stream) {
+  if (!x || !out || n < 1) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL(silu16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (bf16_t*)out, (long long)n);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
@@ -662,14 +676,25 @@ extern "C" int fluxhip_unpack_latents_x3(const void* x, void* out, int64_t out_l
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 
-extern "C" int fluxhip_pixel_linear_x3(const void* x, const void* w, const void* bias, void* out, int64_t out_lo,
-                                       int64_t npix, int Cin, int Cout, int Cpad, float in_div, void* stream) {
+template <bool XH>
+static int run_pixel_linear_x3(const void* x, const void* w, const void* bias, void* out, int64_t out_lo,
+                               int64_t npix, int Cin, int Cout, int Cpad, float in_div, void* stream) {
   if (!x || !w || !out || npix < 1 || Cin < 1 || Cin > 64 || Cout < 1 || Cpad < Cout) return FLUXHIP_EINVAL;
   const long long total = npix * Cpad;
-  hipLaunchKernelGGL(pixel_linear_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(pixel_linear_x3_kernel<XH>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (const float*)w, (const float*)bias, (bf16_t*)out, (long long)out_lo,
                      (long long)npix, Cin, Cout, Cpad, in_div == 0.f ? 1.f : in_div);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_pixel_linear_x3(const void* x, const void* w, const void* bias, void* out, int64_t out_lo,
+                                       int64_t npix, int Cin, int Cout, int Cpad, float in_div, void* stream) {
+  return run_pixel_linear_x3<false>(x, w, bias, out, out_lo, npix, Cin, Cout, Cpad, in_div, stream);
+}
+// x float16 (the latents of a float16=True stable_diffusion/ pipeline); everything else as above
+extern "C" int fluxhip_pixel_linear_x3_f16in(const void* x, const void* w, const void* bias, void* out, int64_t out_lo,
+                                             int64_t npix, int Cin, int Cout, int Cpad, float in_div, void* stream) {
+  return run_pixel_linear_x3<true>(x, w, bias, out, out_lo, npix, Cin, Cout, Cpad, in_div, stream);
 }
 
 extern "C" int fluxhip_softmax_rows_x3(const void* s, void* p, int64_t p_lo, int64_t rows, int cols, int ld,

@@ -18,6 +18,18 @@ FLUXHIP_TILES_X3(X)
 FLUXHIP_TILES_F8(X)
 #undef X
 
+// instantiated in gemm_f16.hip / gemm_conv_f16.hip
+#define X(BM, BN, WM, WN, NS, PIPE) extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_F16>(const GemmParams);
+FLUXHIP_TILES_F16_DENSE(X)
+#undef X
+#define X(BM, BN, WM, WN, NS, PIPE) extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 1, NS, PIPE, FLAG_F16>(const GemmParams);
+FLUXHIP_TILES_F16_CONV(X)
+#undef X
+#define X(BM, BN, WM, WN, NS, PIPE) \
+  extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_F16 | FLAG_LEAN | ((EPI_GEGLU_PAIR + 1) << 8)>(const GemmParams);
+FLUXHIP_TILES_F16_PAIR(X)
+#undef X
+
 namespace {
 
 struct TileCfg {
@@ -32,6 +44,9 @@ struct TileCfg {
   void (*dense_lean)(const GemmParams) = nullptr; // FLAG_LEAN: the same dense kernel with only the transformer-block epilogues compiled in (lean_ok)
   void (*dense_f8_lean)(const GemmParams) = nullptr;   // FLAG_FP8 | FLAG_LEAN: the four transformer-block epilogues (runtime switch)
   void (*dense_pair)(const GemmParams) = nullptr;      // FLAG_LEAN with EPI_GEGLU_PAIR compiled in (the UNet's fused GEGLU Linears)
+  void (*dense_f16)(const GemmParams) = nullptr;       // FLAG_F16 (float16 storage) twins: the tiles of kCands / kConvCands
+  void (*conv_f16)(const GemmParams) = nullptr;
+  void (*dense_pair_f16)(const GemmParams) = nullptr;
   int lean_epi = -1;                              // >= 0: the lean kernel has exactly this epilogue compiled in
   int rs_epi = -1;                                //       (and the reduce-scatter kernel this one)
 };
@@ -95,7 +110,7 @@ constexpr TileCfg with_lean_f8(TileCfg c) {   // fp8: at C5's batch the 256x224 
 }
 
 // index 0 is unused ("auto")
-const TileCfg kCfgs[] = {
+TileCfg kCfgs[] = {
     TileCfg{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1},
     make_cfg_f8<128, 128, 2, 2, 2, 0>(),  // 1: 64 KiB LDS, 2 blocks/CU
     make_cfg_f8<128, 64, 2, 2, 2, 0>(),   // 2: more blocks for N=3072 outputs at small M
@@ -156,7 +171,28 @@ const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-bool g_attr_set[kNumCfgs][9] = {};
+// float16-storage twins, attached by tile shape: a table entry gets the FLAG_F16 kernel of its own (BM, BN, waves, ring, PIPE)
+const bool g_f16_attached = [] {
+  for (int i = 1; i < kNumCfgs; ++i) {
+    TileCfg& c = kCfgs[i];
+#define X(BM, BN, WM, WN, NS, PIPE) \
+    if (c.dense == gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, 0>) c.dense_f16 = gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_F16>;
+    FLUXHIP_TILES_F16_DENSE(X)
+#undef X
+#define X(BM, BN, WM, WN, NS, PIPE) \
+    if (c.dense == gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, 0>) c.conv_f16 = gemm_nt_kernel<BM, BN, WM, WN, 1, NS, PIPE, FLAG_F16>;
+    FLUXHIP_TILES_F16_CONV(X)
+#undef X
+#define X(BM, BN, WM, WN, NS, PIPE)                                 \
+    if (c.dense == gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, 0> && c.dense_pair) \
+      c.dense_pair_f16 = gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_F16 | FLAG_LEAN | ((EPI_GEGLU_PAIR + 1) << 8)>;
+    FLUXHIP_TILES_F16_PAIR(X)
+#undef X
+  }
+  return true;
+}();
+
+bool g_attr_set[kNumCfgs][12] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
 // Tile choice: a time model per tile, fitted to tools/gemm_tune.py sweeps.
@@ -340,17 +376,20 @@ int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbat
   return best_cfg;
 }
 
+// rs: the launch can take the reduce-scatter split-K kernels (lean-eligible gate-residual epilogue on bf16), so a split is
+// priced with the cheap hand-off; every other launch that splits runs the chain and is priced with it
 int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool conv = false, bool x3 = false,
-             bool f8 = false) {
+             bool f8 = false, bool rs = false) {
   if (f8) return pick_from(kF8Cands, group_m, ngroups, nbatch, N, K / 2);   // 128 elements per K-step
   if (x3)   // three passes over K
     return conv ? pick_from(kX3ConvCands, group_m, ngroups, nbatch, N, 3 * K)
                 : pick_from(kX3Cands, group_m, ngroups, nbatch, N, 3 * K);
   return conv ? pick_from(kConvCands, group_m, ngroups, nbatch, N, K, kConvForm)
-              : pick_from<sizeof(kCands) / sizeof(kCands[0]), true>(kCands, group_m, ngroups, nbatch, N, K, kDenseForm);
+              : rs ? pick_from<sizeof(kCands) / sizeof(kCands[0]), true>(kCands, group_m, ngroups, nbatch, N, K, kDenseForm)
+                   : pick_from(kCands, group_m, ngroups, nbatch, N, K, kDenseForm);
 }
 
-int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false, bool f8 = false) {
+int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false, bool f8 = false, bool f16 = false) {
   int cfg_idx = cfg_code & 0xff;
   if (!conv && cfg_idx >= 49 && cfg_idx <= 56) {
     // the ping-pong tiles address their dense operands as scalar base + 32-bit byte offset per (group, batch); an
@@ -374,10 +413,11 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
   if (p.ngroups == 1) p.g[1] = p.g[0];
   p.tiles_m_total = tm_total;
   p.tiles_n = (p.N + c.bn - 1) / c.bn;
-  auto fn = f8 ? c.dense_f8 : x3 ? (conv ? c.conv_x3 : c.dense_x3) : (conv ? c.conv : c.dense);
-  if (!fn) return FLUXHIP_EINVAL;                   // this tile has no fp32-faithful / fp8 instantiation
+  auto fn = f16 ? (conv ? c.conv_f16 : c.dense_f16)
+            : f8 ? c.dense_f8 : x3 ? (conv ? c.conv_x3 : c.dense_x3) : (conv ? c.conv : c.dense);
+  if (!fn) return FLUXHIP_EINVAL;                   // this tile has no fp32-faithful / fp8 / float16 instantiation
 
-  const int slot = f8 ? 4 : (int)conv + 2 * (int)x3;
+  const int slot = f16 ? 9 + (int)conv : f8 ? 4 : (int)conv + 2 * (int)x3;
   if (!g_attr_set[cfg_idx][slot]) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) !=
         hipSuccess)
@@ -399,7 +439,7 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
   // what a FLAG_LEAN instantiation can do (with_lean above): the transformer-block epilogues on the LDS-transposed path
   const bool lean_any = !conv && !x3 && wide && !p.addvec && !p.row_bias && !p.out_f32 &&
                         (p.epi == EPI_BIAS || p.epi == EPI_GELU_TANH || p.epi == EPI_GATE_RES || p.epi == EPI_SPLIT_GELU);
-  const bool lean_ok = lean_any && !f8;
+  const bool lean_ok = lean_any && !f8 && !f16;      // (float16 launches: generic kernels, chain split-K)
   const bool lean_on = g_lean_enabled;
   auto use = [&](void (*k)(const GemmParams), int slot_) {      // a variant kernel of this tile: dynamic LDS attribute once
     if (!g_attr_set[cfg_idx][slot_]) {
@@ -412,12 +452,13 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
   void (*const generic)(const GemmParams) = fn;
   if (p.epi == EPI_GEGLU_PAIR) {                  // lives in its own instantiations: no generic fallback
     if (conv || x3 || f8 || splits != 1 || !wide || p.addvec || p.row_bias || p.out_f32 || !c.dense_pair || p.N % 32) return FLUXHIP_EINVAL;
-    if (!use(c.dense_pair, 8)) return FLUXHIP_ELAUNCH;
+    if (f16 && !c.dense_pair_f16) return FLUXHIP_EINVAL;
+    if (!(f16 ? use(c.dense_pair_f16, 11) : use(c.dense_pair, 8))) return FLUXHIP_ELAUNCH;
   } else
   if (splits == 1 && lean_on) {
     bool ok = true;
     if (lean_ok && c.dense_lean && p.epi == c.lean_epi) ok = use(c.dense_lean, 6);
-    else if (f8 && lean_any && c.dense_f8_lean) ok = use(c.dense_f8_lean, 7);
+    else if (f8 && !f16 && lean_any && c.dense_f8_lean) ok = use(c.dense_f8_lean, 7);
     if (!ok) return FLUXHIP_ELAUNCH;
     g_lean_launches += fn != generic;
   }
@@ -504,11 +545,20 @@ static int params_from_desc(const fluxhip_gemm_desc* d, GemmParams& p, int kalig
   return FLUXHIP_OK;
 }
 
-extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
+// does launch() take the reduce-scatter kernel when this descriptor splits?  (what launch() tests: lean_ok && epi == rs_epi)
+static bool rs_epilogue(const fluxhip_gemm_desc* d) {
+  auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  bool ok = d->epi == FLUXHIP_EPI_GATE_RES && !d->row_bias && !d->out_f32 && d->N % 8 == 0 && d->ldc % 8 == 0;
+  for (int g = 0; g < d->ngroups && ok; ++g)
+    ok = a16(d->g[g].C) && d->g[g].c_bstride % 8 == 0 && a16(d->g[g].res) && a16(d->g[g].gate) && d->g[g].gate_bstride % 8 == 0;
+  return ok;
+}
+
+static int gemm_dense16(const fluxhip_gemm_desc* d, void* stream, bool f16) {
   GemmParams p{};
   if (int rc = params_from_desc(d, p, 64)) return rc;
   const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
-  int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K);
+  int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K, false, false, false, !f16 && rs_epilogue(d));
   if (d->epi == FLUXHIP_EPI_GEGLU_PAIR && d->tile_cfg <= 0) {
     // the pair epilogue exists for 256x256 and 128x256 only: the large tile once it fills most of the chip
     long long t49 = 0;
@@ -516,8 +566,12 @@ extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) {
     t49 *= (d->N + 255) / 256;
     cfg = t49 >= 192 ? 49 : 55;
   }
-  return launch(p, cfg, false, (hipStream_t)stream);
+  return launch(p, cfg, false, (hipStream_t)stream, false, false, f16);
 }
+
+extern "C" int fluxhip_gemm_bf16(const fluxhip_gemm_desc* d, void* stream) { return gemm_dense16(d, stream, false); }
+// the same operator on IEEE float16 storage (v_mfma_f32_16x16x32_f16, fp32 accumulate): the stable_diffusion/ models with float16=True
+extern "C" int fluxhip_gemm_f16(const fluxhip_gemm_desc* d, void* stream) { return gemm_dense16(d, stream, true); }
 
 extern "C" int fluxhip_gemm_fp8(const fluxhip_gemm_desc* d, const fluxhip_fp8_scales* sc, void* stream) {
   GemmParams p{};
@@ -581,7 +635,7 @@ extern "C" int fluxhip_gemm_tile_cfg(const fluxhip_gemm_desc* d) {
   if (!d || d->ngroups < 1 || d->ngroups > 2) return FLUXHIP_EINVAL;
   if (d->tile_cfg > 0) return d->tile_cfg < kNumCfgs ? d->tile_cfg : FLUXHIP_EINVAL;
   const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
-  return pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K);
+  return pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K, false, false, false, rs_epilogue(d));
 }
 
 extern "C" int fluxhip_set_workspace(void* ws, int64_t bytes) {
@@ -627,10 +681,10 @@ extern "C" int fluxhip_gemm_tile_shape(int cfg, int* bm, int* bn, int* threads) 
   return FLUXHIP_OK;
 }
 
-extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bias, const void* res,
-                                   const void* addvec, void* out, int B, int Hs, int Ws, int Cin,
-                                   int Cout, int ksize, int stride, int pad, int ups, int epi,
-                                   const void* zero16, void* stream) {
+static int conv2d_16(const void* x, const void* w, const void* bias, const void* res,
+                     const void* addvec, void* out, int B, int Hs, int Ws, int Cin,
+                     int Cout, int ksize, int stride, int pad, int ups, int epi,
+                     const void* zero16, void* stream, bool f16) {
   if (!x || !w || !out || !zero16) return FLUXHIP_EINVAL;
   if (Cin % 64 || Cout % 4 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
     return FLUXHIP_EINVAL;
@@ -667,7 +721,20 @@ extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bia
   static const int forced = [] { const char* e = getenv("FLUXHIP_CONV_CFG"); return e ? atoi(e) : 0; }();   // tuning knob
   int cfg = forced > 0 ? forced : pick_cfg(&t.M, 1, 1, Cout, p.K, true);
   if (forced <= 0 && ups && (cfg & 0xff) == 49) cfg = (cfg & ~0xff) | 15;     // fused-upsample loader: the plain ring is 2-4 % faster
-  return launch(p, cfg, true, (hipStream_t)stream);
+  return launch(p, cfg, true, (hipStream_t)stream, false, false, f16);
+}
+
+extern "C" int fluxhip_conv2d_bf16(const void* x, const void* w, const void* bias, const void* res,
+                                   const void* addvec, void* out, int B, int Hs, int Ws, int Cin,
+                                   int Cout, int ksize, int stride, int pad, int ups, int epi,
+                                   const void* zero16, void* stream) {
+  return conv2d_16(x, w, bias, res, addvec, out, B, Hs, Ws, Cin, Cout, ksize, stride, pad, ups, epi, zero16, stream, false);
+}
+extern "C" int fluxhip_conv2d_f16(const void* x, const void* w, const void* bias, const void* res,
+                                  const void* addvec, void* out, int B, int Hs, int Ws, int Cin,
+                                  int Cout, int ksize, int stride, int pad, int ups, int epi,
+                                  const void* zero16, void* stream) {
+  return conv2d_16(x, w, bias, res, addvec, out, B, Hs, Ws, Cin, Cout, ksize, stride, pad, ups, epi, zero16, stream, true);
 }
 
 extern "C" int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int64_t w_lo, const void* bias,

@@ -143,8 +143,18 @@ enum GemmFlags : int {
   // they share the kernel (build-to-build A/B, tools/lib_ab.py: mlp0 87.1 -> 88.7 us, linear1 150.0 -> 153.0 us), so only the
   // tiles the picker splits (256 x 192, 256 x 256) carry a second kernel with it.
   FLAG_RS = 16,
+  // float16 storage (the stable_diffusion/ path with float16=True, the reference's flux_app.py:77-79): operands, bias,
+  // residual, gate, addvec and outputs are IEEE half; v_mfma_f32_16x16x32_f16 issues at the bf16 rate; accumulation stays fp32
+  FLAG_F16 = 64,
   FLAG_LEAN = 32,    // dense bf16 only: the epilogues, operands and hand-offs the Flux / transformer-block launches use, nothing else compiled in (see gemm.hip lean_ok)
 };
+
+// one 16x16x32 MFMA on 16-bit operands of the kernel's storage type (bf16, or float16 under FLAG_F16)
+template <bool H>
+DEVINL f32x4 mfma16(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+  if constexpr (H) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 template <int N>
 DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -262,6 +272,8 @@ void gemm_nt_kernel(const GemmParams p) {
   const int N = p.N, K = p.K;
   constexpr bool X3 = (FLAGS & FLAG_SPLIT) != 0;
   constexpr bool F8 = (FLAGS & FLAG_FP8) != 0;
+  constexpr bool F16 = (FLAGS & FLAG_F16) != 0;    // 16-bit storage type: false = bfloat16, true = float16
+  static_assert(!(F16 && (X3 || F8 || (FLAGS & FLAG_RS) != 0)), "float16 storage: plain dense / conv kernels");
   constexpr int ESZ = F8 ? 1 : 2;                  // bytes per operand element
   static_assert(!(F8 && (X3 || AMODE != 0)), "fp8: dense operands, no split mode");
   static_assert(!F8 || PIPE == 0 || PIPE == 6, "fp8 variants exist for the simple ring and the ping-pong schedule");
@@ -439,7 +451,7 @@ void gemm_nt_kernel(const GemmParams p) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16<F16>(wf[j], af[i], acc[i][j]);
   };
 
   // FLAG_FP8: the two 16-byte halves of every fragment make one 32-byte operand of the 16x16x128 fp8 MFMA
@@ -849,7 +861,7 @@ void gemm_nt_kernel(const GemmParams p) {
         constexpr int np = decltype(np_tag)::value, nrd = decltype(nrd_tag)::value;
         static_for<0, NM>([&](auto I) {
           constexpr int i = I.value / NJ, j = I.value % NJ, idx = I.value + 1;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<F16>(wf[j], af[i], acc[i][j]);
           if constexpr (idx <= nrd) {
             __builtin_amdgcn_sched_barrier(0);
             rd(std::integral_constant<int, idx - 1>{});
@@ -1211,16 +1223,16 @@ void gemm_nt_kernel(const GemmParams p) {
         }
         if (epi == EPI_GATE_RES) {
           const u32x2 rh = *(const u32x2*)(gRes + idx), rl = *(const u32x2*)(gRes + idx + p.res_lo);
-          v[0] += bf_lo(rh[0]) + bf_lo(rl[0]);
-          v[1] += bf_hi(rh[0]) + bf_hi(rl[0]);
-          v[2] += bf_lo(rh[1]) + bf_lo(rl[1]);
-          v[3] += bf_hi(rh[1]) + bf_hi(rl[1]);
+          v[0] += e_lo<F16>(rh[0]) + e_lo<F16>(rl[0]);
+          v[1] += e_hi<F16>(rh[0]) + e_hi<F16>(rl[0]);
+          v[2] += e_lo<F16>(rh[1]) + e_lo<F16>(rl[1]);
+          v[3] += e_hi<F16>(rh[1]) + e_hi<F16>(rl[1]);
         }
         u32x2 oh, ol;
-        oh[0] = pack_bf16x2(v[0], v[1]);
-        oh[1] = pack_bf16x2(v[2], v[3]);
-        ol[0] = pack_bf16x2(v[0] - bf_lo(oh[0]), v[1] - bf_hi(oh[0]));
-        ol[1] = pack_bf16x2(v[2] - bf_lo(oh[1]), v[3] - bf_hi(oh[1]));
+        oh[0] = e_pack<F16>(v[0], v[1]);
+        oh[1] = e_pack<F16>(v[2], v[3]);
+        ol[0] = e_pack<F16>(v[0] - e_lo<F16>(oh[0]), v[1] - e_hi<F16>(oh[0]));
+        ol[1] = e_pack<F16>(v[2] - e_lo<F16>(oh[1]), v[3] - e_hi<F16>(oh[1]));
         *(u32x2*)(gC + idx) = oh;
         *(u32x2*)(gC + idx + p.c_lo) = ol;
         gs[j] += (v[0] + v[1]) + (v[2] + v[3]);
@@ -1260,7 +1272,7 @@ void gemm_nt_kernel(const GemmParams p) {
       bcol[j] = colb ? *(const u32x2*)(gBias + n4) : u32x2{0u, 0u};
     }
 #pragma unroll
-    for (int i = 0; i < MI; ++i) brow[i] = rowb ? bf2f(gBias[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)]) : 0.f;
+    for (int i = 0; i < MI; ++i) brow[i] = rowb ? e2f<F16>(gBias[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)]) : 0.f;
   }
   // FLAG_FP8: dequantisation scales of this lane's rows (activation, per token) and columns (weight, per channel)
   float asc[F8 ? MI : 1];
@@ -1276,22 +1288,22 @@ void gemm_nt_kernel(const GemmParams p) {
   // (ADDVEC is a compile-time tag so the common path carries no per-tile branch or integer division)
   auto biased = [&](auto addvec_tag, int i, int j, int m, int n4, float (&v)[4]) {
     if constexpr (F8) {
-      v[0] = acc[i][j][0] * (asc[i] * wsc[j][0]) + (bf_lo(bcol[j][0]) + brow[i]);
-      v[1] = acc[i][j][1] * (asc[i] * wsc[j][1]) + (bf_hi(bcol[j][0]) + brow[i]);
-      v[2] = acc[i][j][2] * (asc[i] * wsc[j][2]) + (bf_lo(bcol[j][1]) + brow[i]);
-      v[3] = acc[i][j][3] * (asc[i] * wsc[j][3]) + (bf_hi(bcol[j][1]) + brow[i]);
+      v[0] = acc[i][j][0] * (asc[i] * wsc[j][0]) + (e_lo<F16>(bcol[j][0]) + brow[i]);
+      v[1] = acc[i][j][1] * (asc[i] * wsc[j][1]) + (e_hi<F16>(bcol[j][0]) + brow[i]);
+      v[2] = acc[i][j][2] * (asc[i] * wsc[j][2]) + (e_lo<F16>(bcol[j][1]) + brow[i]);
+      v[3] = acc[i][j][3] * (asc[i] * wsc[j][3]) + (e_hi<F16>(bcol[j][1]) + brow[i]);
     } else {
-    v[0] = acc[i][j][0] * alpha + (bf_lo(bcol[j][0]) + brow[i]);
-    v[1] = acc[i][j][1] * alpha + (bf_hi(bcol[j][0]) + brow[i]);
-    v[2] = acc[i][j][2] * alpha + (bf_lo(bcol[j][1]) + brow[i]);
-    v[3] = acc[i][j][3] * alpha + (bf_hi(bcol[j][1]) + brow[i]);
+    v[0] = acc[i][j][0] * alpha + (e_lo<F16>(bcol[j][0]) + brow[i]);
+    v[1] = acc[i][j][1] * alpha + (e_hi<F16>(bcol[j][0]) + brow[i]);
+    v[2] = acc[i][j][2] * alpha + (e_lo<F16>(bcol[j][1]) + brow[i]);
+    v[3] = acc[i][j][3] * alpha + (e_hi<F16>(bcol[j][1]) + brow[i]);
     }
     if constexpr (decltype(addvec_tag)::value) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
       u32x2 aw = *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
-      v[0] = rbf(v[0]) + bf_lo(aw[0]);
-      v[1] = rbf(v[1]) + bf_hi(aw[0]);
-      v[2] = rbf(v[2]) + bf_lo(aw[1]);
-      v[3] = rbf(v[3]) + bf_hi(aw[1]);
+      v[0] = e_rnd<F16>(v[0]) + e_lo<F16>(aw[0]);
+      v[1] = e_rnd<F16>(v[1]) + e_hi<F16>(aw[0]);
+      v[2] = e_rnd<F16>(v[2]) + e_lo<F16>(aw[1]);
+      v[3] = e_rnd<F16>(v[3]) + e_hi<F16>(aw[1]);
     }
   };
   // activation / gate / residual on NV consecutive columns of row m starting at column n
@@ -1311,22 +1323,22 @@ void gemm_nt_kernel(const GemmParams p) {
         const uint32_t* gp = (const uint32_t*)(gGate + (long long)b * gate_bs + n);
         for (int r = 0; r < NV; r += 2) {
           const uint32_t rw = rp[r >> 1], gw = gp[r >> 1];
-          v[r] = bf_lo(rw) + rbf(bf_lo(gw) * v[r]);
-          v[r + 1] = bf_hi(rw) + rbf(bf_hi(gw) * v[r + 1]);
+          v[r] = e_lo<F16>(rw) + e_rnd<F16>(e_lo<F16>(gw) * v[r]);
+          v[r + 1] = e_hi<F16>(rw) + e_rnd<F16>(e_hi<F16>(gw) * v[r + 1]);
         }
       } else {
         for (int r = 0; r < NV; r += 2) {
           const uint32_t rw = rp[r >> 1];
-          v[r] = bf_lo(rw) + v[r];
-          v[r + 1] = bf_hi(rw) + v[r + 1];
+          v[r] = e_lo<F16>(rw) + v[r];
+          v[r + 1] = e_hi<F16>(rw) + v[r + 1];
         }
       }
     } else if (!LEAN && epi == EPI_GEGLU) {   // out = res * gelu_erf(acc + bias)   (y_a * nn.gelu(y_b))
       const uint32_t* rp = (const uint32_t*)(gRes + (long long)b * c_bs + (long long)m * p.ldc + n);
       for (int r = 0; r < NV; r += 2) {
         const uint32_t rw = rp[r >> 1];
-        v[r] = bf_lo(rw) * rbf(gelu_erf_f(v[r]));
-        v[r + 1] = bf_hi(rw) * rbf(gelu_erf_f(v[r + 1]));
+        v[r] = e_lo<F16>(rw) * e_rnd<F16>(gelu_erf_f(v[r]));
+        v[r + 1] = e_hi<F16>(rw) * e_rnd<F16>(gelu_erf_f(v[r + 1]));
       }
     } else if (epi == EPI_SPLIT_GELU) {
       if (n >= p.n_split) {
@@ -1358,8 +1370,8 @@ void gemm_nt_kernel(const GemmParams p) {
           float v[4];
           biased(addvec_tag, i, j, m, n4, v);
           u32x2 o;
-          o[0] = pack_bf16x2(v[0], v[1]);
-          o[1] = pack_bf16x2(v[2], v[3]);
+          o[0] = e_pack<F16>(v[0], v[1]);
+          o[1] = e_pack<F16>(v[2], v[3]);
           const int ch = cswz(j * 2 + (q4 >> 1), row);
           *(u32x2*)(my_lds + row * (NCH * 16) + ch * 16 + (q4 & 1) * 8) = o;
         }
@@ -1392,7 +1404,7 @@ void gemm_nt_kernel(const GemmParams p) {
         u32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          o[r] = pack_bf16x2(bf_lo(xa[r]) * rbf(gelu_erf_f(bf_lo(xg[r]))), bf_hi(xa[r]) * rbf(gelu_erf_f(bf_hi(xg[r]))));
+          o[r] = e_pack<F16>(e_lo<F16>(xa[r]) * e_rnd<F16>(gelu_erf_f(e_lo<F16>(xg[r]))), e_hi<F16>(xa[r]) * e_rnd<F16>(gelu_erf_f(e_hi<F16>(xg[r]))));
         *(u32x4*)(gC + (long long)b * c_bs + (long long)m * p.ldc + nout) = o;
       }
     } else {
@@ -1422,10 +1434,10 @@ void gemm_nt_kernel(const GemmParams p) {
       if (epi != EPI_BIAS) {
         float v[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { v[2 * r] = bf_lo(x[r]); v[2 * r + 1] = bf_hi(x[r]); }
+        for (int r = 0; r < 4; ++r) { v[2 * r] = e_lo<F16>(x[r]); v[2 * r + 1] = e_hi<F16>(x[r]); }
         finish(v, 8, m, n8, dst);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = pack_bf16x2(v[2 * r], v[2 * r + 1]);
+        for (int r = 0; r < 4; ++r) o[r] = e_pack<F16>(v[2 * r], v[2 * r + 1]);
       } else {
         dst = gC + (long long)b * c_bs + (long long)m * p.ldc + n8;
       }
@@ -1450,12 +1462,12 @@ void gemm_nt_kernel(const GemmParams p) {
           continue;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = e_rnd<F16>(v[r]);
         bf16_t* dst;
         finish(v, 4, m, n4, dst);
         u32x2 o;
-        o[0] = pack_bf16x2(v[0], v[1]);
-        o[1] = pack_bf16x2(v[2], v[3]);
+        o[0] = e_pack<F16>(v[0], v[1]);
+        o[1] = e_pack<F16>(v[2], v[3]);
         *(u32x2*)dst = o;
       }
     }
@@ -1487,12 +1499,12 @@ void gemm_nt_kernel(const GemmParams p) {
             float v[4];
             biased(std::false_type{}, i, j, m, n4, v);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = e_rnd<F16>(v[r]);
             bf16_t* dst;
             finish(v, 4, m, n4, dst);
             u32x2 o;
-            o[0] = pack_bf16x2(v[0], v[1]);
-            o[1] = pack_bf16x2(v[2], v[3]);
+            o[0] = e_pack<F16>(v[0], v[1]);
+            o[1] = e_pack<F16>(v[2], v[3]);
             *(u32x2*)dst = o;
           }
       }

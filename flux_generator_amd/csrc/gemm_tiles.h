@@ -31,3 +31,16 @@
   X(128, 128, 2, 2, 2, 0) X(128, 64, 2, 2, 2, 0) X(64, 128, 2, 2, 2, 0) X(64, 64, 2, 2, 2, 0)                 \
   X(256, 256, 2, 4, 2, 0) X(256, 128, 4, 2, 2, 6) X(128, 128, 2, 4, 2, 6) X(256, 160, 4, 2, 2, 6)             \
   X(128, 256, 2, 4, 2, 6) X(256, 224, 4, 2, 2, 6) X(256, 192, 4, 2, 2, 6) X(256, 256, 4, 2, 2, 6)
+
+// float16-storage (FLAG_F16) kernels: the tiles the dense / conv pickers can return (kCands, kConvCands in gemm.hip), the
+// plain-ring 256 x 256 conv tile of the fused-upsample loader, and the two tiles that carry the GEGLU pair epilogue.
+// (BM, BN, WM, WN, NSTAGE, PIPE); instantiated in gemm_f16.hip (dense, pair) and gemm_conv_f16.hip (conv).
+#define FLUXHIP_TILES_F16_DENSE(X)                                                                            \
+  X(256, 256, 4, 2, 2, 6) X(256, 224, 4, 2, 2, 6) X(256, 192, 4, 2, 2, 6) X(256, 160, 4, 2, 2, 6)             \
+  X(256, 128, 4, 2, 3, 5) X(128, 256, 2, 4, 2, 6) X(128, 128, 2, 4, 3, 5) X(128, 128, 2, 2, 2, 1)             \
+  X(128, 64, 2, 2, 2, 1) X(64, 128, 2, 2, 2, 1) X(64, 64, 2, 2, 2, 0)
+#define FLUXHIP_TILES_F16_CONV(X)                                                                             \
+  X(256, 256, 4, 2, 2, 6) X(256, 224, 4, 2, 2, 6) X(256, 192, 4, 2, 2, 6) X(256, 160, 4, 2, 2, 6)             \
+  X(256, 128, 4, 2, 2, 1) X(128, 256, 2, 4, 2, 6) X(128, 128, 2, 2, 2, 1) X(128, 64, 2, 2, 2, 1)              \
+  X(64, 128, 2, 2, 2, 1) X(64, 64, 2, 2, 2, 0) X(256, 256, 4, 2, 2, 1)
+#define FLUXHIP_TILES_F16_PAIR(X) X(256, 256, 4, 2, 2, 6) X(128, 256, 2, 4, 2, 6)

@@ -15,13 +15,14 @@
 namespace {
 
 // 8 channels of one pixel as float32: a bf16 chunk, or (SPLIT) the sum of the hi and lo plane chunks
-template <bool SPLIT>
+// (H: the 16-bit storage type is IEEE float16 instead of bfloat16; never together with SPLIT)
+template <bool SPLIT, bool H = false>
 DEVINL void load8(const bf16_t* p, long long lo_off, float (&v)[8]) {
   const u32x4 h = *(const u32x4*)p;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    v[2 * e] = bf_lo(h[e]);
-    v[2 * e + 1] = bf_hi(h[e]);
+    v[2 * e] = e_lo<H>(h[e]);
+    v[2 * e + 1] = e_hi<H>(h[e]);
   }
   if constexpr (SPLIT) {
     const u32x4 l = *(const u32x4*)(p + lo_off);
@@ -34,7 +35,7 @@ DEVINL void load8(const bf16_t* p, long long lo_off, float (&v)[8]) {
 }
 
 // CB = channel chunks (of 8 channels) handled per block along blockIdx.z; 256 % CB == 0
-template <int CB, bool SPLIT = false>
+template <int CB, bool SPLIT = false, bool H = false>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x,
                                                          float* __restrict__ ws, int HW, int C,
                                                          int nchunks, int ppb, long long x_lo = 0) {
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     for (int u = 0; u < U; ++u) {
       const int pp = p + u * ROWS;
       if (pp < p1) {
-        load8<SPLIT>(x + ((long long)b * HW + pp) * C + cc * 8, x_lo, w[u]);
+        load8<SPLIT, H>(x + ((long long)b * HW + pp) * C + cc * 8, x_lo, w[u]);
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[u][e] = 0.f;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(float* __restrict__ ws
 }
 
 // SPLIT: x / out are hi+lo plane pairs, gamma / beta are float32
-template <int CB, bool SPLIT = false>
+template <int CB, bool SPLIT = false, bool H = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x,
                                                        const float* __restrict__ ws,
                                                        const bf16_t* __restrict__ gamma,
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     const u32x4 bw = *((const u32x4*)beta + cc);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      gaf[e] = (e & 1) ? bf_hi(gw[e >> 1]) : bf_lo(gw[e >> 1]);
-      bef[e] = (e & 1) ? bf_hi(bw[e >> 1]) : bf_lo(bw[e >> 1]);
+      gaf[e] = (e & 1) ? e_hi<H>(gw[e >> 1]) : e_lo<H>(gw[e >> 1]);
+      bef[e] = (e & 1) ? e_hi<H>(bw[e >> 1]) : e_lo<H>(bw[e >> 1]);
     }
   }
   float fa[8], fc[8];
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int pp = min(p + u * ROWS, p1 - 1);
-      load8<SPLIT>(x + ((long long)b * HW + pp) * C + cc * 8, x_lo, w[u]);
+      load8<SPLIT, H>(x + ((long long)b * HW + pp) * C + cc * 8, x_lo, w[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
           y0 = SPLIT ? y0 / (1.0f + expf(-y0)) : silu_f(y0);       // fp32-faithful path: full-precision exp
           y1 = SPLIT ? y1 / (1.0f + expf(-y1)) : silu_f(y1);
         }
-        o[e] = pack_bf16x2(y0, y1);
+        o[e] = e_pack<H>(y0, y1);
         if constexpr (SPLIT) ol[e] = pack_bf16x2(y0 - bf_lo(o[e]), y1 - bf_hi(o[e]));
       }
       bf16_t* dst = out + ((long long)b * HW + pp) * C + cc * 8;
@@ -212,9 +213,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 
 }  // namespace
 
-extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, const void* beta,
-                                           void* out, int B, int HW, int C, int G, float eps,
-                                           int silu, void* ws, int64_t ws_bytes, void* stream) {
+template <bool H>
+static int run_groupnorm_silu(const void* x, const void* gamma, const void* beta,
+                              void* out, int B, int HW, int C, int G, float eps,
+                              int silu, void* ws, int64_t ws_bytes, void* stream) {
   if (!x || !gamma || !beta || !out || !ws) return FLUXHIP_EINVAL;
   if (B < 1 || HW < 1 || C % 8 || G < 1 || G > 64 || C % G) return FLUXHIP_EINVAL;
   const int cpr = C / 8;
@@ -230,11 +232,11 @@ extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, con
   dim3 grid(nchunks, B, cpr / cb), block(256);
 #define GN_RUN(CB)                                                                                   \
   do {                                                                                               \
-    hipLaunchKernelGGL((gn_partial_kernel<CB>), grid, block, 0, s, (const bf16_t*)x, (float*)ws, HW, \
+    hipLaunchKernelGGL((gn_partial_kernel<CB, false, H>), grid, block, 0, s, (const bf16_t*)x, (float*)ws, HW, \
                        C, nchunks, ppb);                                                             \
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(256), 0, s, (float*)ws, B, C, G,         \
                        nchunks, (float)HW * (float)(C / G), eps);                                    \
-    hipLaunchKernelGGL((gn_apply_kernel<CB>), grid, block, 0, s, (const bf16_t*)x, (const float*)ws, \
+    hipLaunchKernelGGL((gn_apply_kernel<CB, false, H>), grid, block, 0, s, (const bf16_t*)x, (const float*)ws, \
                        (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)out, HW, C, G, nchunks,   \
                        silu, ppb);                                                                   \
   } while (0)
@@ -244,6 +246,18 @@ extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, con
   else GN_RUN(8);
 #undef GN_RUN
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_groupnorm_silu_bf16(const void* x, const void* gamma, const void* beta,
+                                           void* out, int B, int HW, int C, int G, float eps,
+                                           int silu, void* ws, int64_t ws_bytes, void* stream) {
+  return run_groupnorm_silu<false>(x, gamma, beta, out, B, HW, C, G, eps, silu, ws, ws_bytes, stream);
+}
+// float16 storage (x, gamma, beta, out are IEEE half; statistics float32 as before)
+extern "C" int fluxhip_groupnorm_silu_f16(const void* x, const void* gamma, const void* beta,
+                                          void* out, int B, int HW, int C, int G, float eps,
+                                          int silu, void* ws, int64_t ws_bytes, void* stream) {
+  return run_groupnorm_silu<true>(x, gamma, beta, out, B, HW, C, G, eps, silu, ws, ws_bytes, stream);
 }
 
 extern "C" int fluxhip_groupnorm_silu_x3(const void* x, int64_t x_lo, const void* gamma, const void* beta,

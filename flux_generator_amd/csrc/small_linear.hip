@@ -13,7 +13,7 @@
 
 namespace {
 
-template <int ROWS, int MAXB>
+template <int ROWS, int MAXB, bool H = false>
 __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restrict__ x,
                                                            const bf16_t* __restrict__ W,
                                                            const bf16_t* __restrict__ bias,
@@ -45,19 +45,19 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restr
         float xf[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          xf[2 * e] = bf_lo(xv[e]);
-          xf[2 * e + 1] = bf_hi(xv[e]);
+          xf[2 * e] = e_lo<H>(xv[e]);
+          xf[2 * e + 1] = e_hi<H>(xv[e]);
         }
         if (silu_in) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) xf[e] = rbf(silu_f(xf[e]));
+          for (int e = 0; e < 8; ++e) xf[e] = e_rnd<H>(silu_f(xf[e]));
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            acc[r][b] += bf_lo(wv[r][e]) * xf[2 * e];
-            acc[r][b] += bf_hi(wv[r][e]) * xf[2 * e + 1];
+            acc[r][b] += e_lo<H>(wv[r][e]) * xf[2 * e];
+            acc[r][b] += e_hi<H>(wv[r][e]) * xf[2 * e + 1];
           }
         }
       }
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restr
         float s = wave_sum(acc[r][b]);
         int n = n0 + r;
         if (lane == 0 && n < N) {
-          if (bias) s += bf2f(bias[n]);
+          if (bias) s += e2f<H>(bias[n]);
           long long o = (long long)b * N + n;
-          if (accum) s = bf2f(out[o]) + rbf(s);
-          out[o] = f2bf(s);
+          if (accum) s = e2f<H>(out[o]) + e_rnd<H>(s);
+          out[o] = f2e<H>(s);
         }
       }
     }
@@ -83,23 +83,33 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restr
 
 }  // namespace
 
-extern "C" int fluxhip_small_linear_bf16(const void* x, const void* W, const void* bias, void* out,
-                                         int B, int N, int K, int silu_in, int accum,
-                                         void* stream) {
+template <bool H>
+static int small_linear_16(const void* x, const void* W, const void* bias, void* out,
+                           int B, int N, int K, int silu_in, int accum, void* stream) {
   if (!x || !W || !out || B < 1 || B > 16 || N < 1 || K < 8 || K % 8) return FLUXHIP_EINVAL;
   constexpr int ROWS = 4;
   const int waves = (N + ROWS - 1) / ROWS;
   dim3 grid((waves + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (B <= 1)
-    hipLaunchKernelGGL((small_linear_kernel<ROWS, 1>), grid, block, 0, s, (const bf16_t*)x,
+    hipLaunchKernelGGL((small_linear_kernel<ROWS, 1, H>), grid, block, 0, s, (const bf16_t*)x,
                        (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)out, B, N, K, silu_in, accum);
   else if (B <= 4)
-    hipLaunchKernelGGL((small_linear_kernel<ROWS, 4>), grid, block, 0, s, (const bf16_t*)x,
+    hipLaunchKernelGGL((small_linear_kernel<ROWS, 4, H>), grid, block, 0, s, (const bf16_t*)x,
                        (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)out, B, N, K, silu_in, accum);
   else
-    hipLaunchKernelGGL((small_linear_kernel<2, 16>), dim3(((N + 1) / 2 + 3) / 4), block, 0, s,
+    hipLaunchKernelGGL((small_linear_kernel<2, 16, H>), dim3(((N + 1) / 2 + 3) / 4), block, 0, s,
                        (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)out, B, N,
                        K, silu_in, accum);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
+extern "C" int fluxhip_small_linear_bf16(const void* x, const void* W, const void* bias, void* out,
+                                         int B, int N, int K, int silu_in, int accum, void* stream) {
+  return small_linear_16<false>(x, W, bias, out, B, N, K, silu_in, accum, stream);
+}
+// float16 storage (stable_diffusion/ with float16=True): same kernel, IEEE half elements
+extern "C" int fluxhip_small_linear_f16(const void* x, const void* W, const void* bias, void* out,
+                                        int B, int N, int K, int silu_in, int accum, void* stream) {
+  return small_linear_16<true>(x, W, bias, out, B, N, K, silu_in, accum, stream);
 }

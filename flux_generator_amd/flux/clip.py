@@ -53,7 +53,12 @@ class CLIPOutput:
 
 
 class CLIPTextModel:
-    def __init__(self, config: CLIPTextModelConfig, device: Union[str, torch.device] = "cuda"):
+    def __init__(self, config: CLIPTextModelConfig, device: Union[str, torch.device] = "cuda", dtype: torch.dtype = BF16):
+        """dtype: 16-bit storage type — torch.bfloat16 (the Flux pipeline's dtype, flux/flux.py:24) or torch.float16 (the
+        stable_diffusion/ towers under float16=True, stable_diffusion/.../model_io.py:171-174)."""
+        if dtype not in (BF16, torch.float16):
+            raise ValueError("CLIPTextModel dtype must be torch.bfloat16 or torch.float16")
+        self.dtype = dtype
         if config.model_dims // config.num_heads != 64:
             raise ValueError("libfluxhip CLIP attention is built for head_dim 64")
         if config.hidden_act not in _ACT_EPI:
@@ -76,7 +81,7 @@ class CLIPTextModel:
             shp[f"{p}.linear2.weight"] = (D, 4 * D); shp[f"{p}.linear2.bias"] = (D,)
         if config.projection_dim is not None:
             shp["text_projection.weight"] = (config.projection_dim, D)
-        self._params = {k: torch.empty(*v, dtype=BF16, device=self.device) for k, v in shp.items()}
+        self._params = {k: torch.empty(*v, dtype=self.dtype, device=self.device) for k, v in shp.items()}
         self._qk: Dict[int, tuple] = {}
 
     def parameters(self):
@@ -102,11 +107,11 @@ class CLIPTextModel:
             if "layer_norm" in name:
                 t.fill_(1.0 if name.endswith(".weight") else 0.0)
             elif "embedding" in name:
-                t.copy_((torch.randn(t.shape, generator=g, device=self.device) * 0.5).to(BF16))
+                t.copy_((torch.randn(t.shape, generator=g, device=self.device) * 0.5).to(self.dtype))
             else:
                 base = name.rsplit(".", 1)[0]
                 k = 1.0 / math.sqrt(self._params[f"{base}.weight"].shape[1])
-                t.copy_(((torch.rand(t.shape, generator=g, device=self.device) * 2 - 1) * k).to(BF16))
+                t.copy_(((torch.rand(t.shape, generator=g, device=self.device) * 2 - 1) * k).to(self.dtype))
         return self.finalize()
 
     def load_weights(self, weights, strict: bool = True) -> "CLIPTextModel":
@@ -119,7 +124,7 @@ class CLIPTextModel:
                 continue
             if tuple(self._params[k].shape) != tuple(w.shape):
                 raise ValueError(f"Shape mismatch for {k}")
-            self._params[k].copy_(w.to(device=self.device, dtype=BF16))
+            self._params[k].copy_(w.to(device=self.device, dtype=self.dtype))
             seen.add(k)
         if strict and set(self._params) - seen:
             raise ValueError(f"Missing parameters: {sorted(set(self._params) - seen)[:5]} ...")
@@ -145,9 +150,9 @@ class CLIPTextModel:
         Np = (N + 7) // 8 * 8                                    # rows padded for the V^T GEMM's N granularity
         h = ops.embedding(tok, P["token_embedding.weight"], P["position_embedding.weight"])      # [B,N,D]
         Tpad = (N + 63) // 64 * 64
-        vt = torch.zeros(B, D, Tpad, dtype=BF16, device=self.device)
-        ypad = torch.zeros(B, Np, D, dtype=BF16, device=self.device)
-        o = torch.empty(B, N, D, dtype=BF16, device=self.device)
+        vt = torch.zeros(B, D, Tpad, dtype=self.dtype, device=self.device)
+        ypad = torch.zeros(B, Np, D, dtype=self.dtype, device=self.device)
+        o = torch.empty(B, N, D, dtype=self.dtype, device=self.device)
         hs = []
         for i in range(c.num_layers):
             p = f"layers.{i}"
@@ -157,7 +162,8 @@ class CLIPTextModel:
             ypad[:, :N].copy_(y)
             ops.gemm(make_gemm_desc([dict(A=P[f"{p}.attention.value_proj.weight"].data_ptr(), W=ypad.data_ptr(),
                                           bias=P[f"{p}.attention.value_proj.bias"].data_ptr(), C=vt.data_ptr(), a_bstride=0,
-                                          w_bstride=Np * D, c_bstride=D * Tpad, M=D)], B, Np, D, D, Tpad, row_bias=True))
+                                          w_bstride=Np * D, c_bstride=D * Tpad, M=D)], B, Np, D, D, Tpad, row_bias=True),
+                     self.dtype == torch.float16)
             st = (N * 2 * D, 64, 2 * D)
             ops.attention_masked(qk, qk[..., D:], vt, o, B, H, N, N, Tpad, st, st, D, 64 ** -0.5, causal=True)
             h = ops.linear(o, P[f"{p}.attention.out_proj.weight"], P[f"{p}.attention.out_proj.bias"], epi=EPI_GATE_RES, res=h)

@@ -44,9 +44,39 @@ def _bf16c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+F16 = torch.float16
+
+
+def _e16(*named) -> bool:
+    """Operands of an operator that exists for both 16-bit storage types (bfloat16, and IEEE float16 for the
+    stable_diffusion/ models with float16=True): all given (tensor, name) pairs must be contiguous and of ONE of the two
+    types.  Returns True for float16 (-> the `_f16` entry point of include/fluxhip.h)."""
+    dt = None
+    for i, (t, name) in enumerate(named):
+        if t is None:
+            continue
+        if t.dtype not in (BF16, F16) or (i < 2 and not t.is_contiguous()):      # (the first two are the streamed operands)
+            raise FluxHipError(f"{name} must be a contiguous bfloat16 or float16 tensor")
+        if dt is None:
+            dt = t.dtype
+        elif t.dtype != dt:
+            raise FluxHipError(f"{name} is {t.dtype} but the other operands are {dt}: no mixed 16-bit types")
+    return dt == F16
+
+
+def _fn(name: str, f16: bool):
+    """The bf16 entry point `name`, or its float16 twin."""
+    if f16:
+        name = {"fluxhip_sincos_embed_f32": "fluxhip_sincos_embed_f32_f16",
+                "fluxhip_pixel_linear_x3": "fluxhip_pixel_linear_x3_f16in"}.get(name, name.replace("_bf16", "_f16"))
+    return getattr(_lib.load(), name), name
+
+
 # ------------------------------------------------------------------------------------------------
-def gemm(desc: GemmDesc) -> None:
-    _check(_lib.load().fluxhip_gemm_bf16(desc, _stream()), "fluxhip_gemm_bf16")
+def gemm(desc: GemmDesc, f16: bool = False) -> None:
+    """f16: the descriptor's 16-bit operands are IEEE float16 (fluxhip_gemm_f16) instead of bfloat16."""
+    fn, name = _fn("fluxhip_gemm_bf16", f16)
+    _check(fn(desc, _stream()), name)
 
 
 def make_gemm_desc(groups: Sequence[dict], nbatch: int, N: int, K: int, lda: int, ldc: int, epi: int = EPI_BIAS,
@@ -72,15 +102,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, e
            out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            gate: Optional[torch.Tensor] = None, tile_cfg: int = 0) -> torch.Tensor:
     """y = epi(x @ w.T + b) for x [..., K], w [N, K]; gate [N] (broadcast over rows) optional."""
-    _bf16c(x, "x"); _bf16c(w, "w")
+    f16 = _e16((x, "x"), (w, "w"), (b, "bias"), (res, "res"), (gate, "gate"), (out, "out"))
     K = x.shape[-1]
     N = w.shape[0]
     M = x.numel() // K
     Nout = N // 2 if epi == EPI_GEGLU_PAIR else N      # the pair epilogue multiplies value and gate columns: N / 2 outputs
     if out is None:
-        out = torch.empty(*x.shape[:-1], Nout, dtype=BF16, device=x.device)
+        out = torch.empty(*x.shape[:-1], Nout, dtype=x.dtype, device=x.device)
     g = dict(A=_p(x), W=_p(w), bias=_p(b), C=_p(out), res=_p(res), gate=_p(gate), M=M)
-    gemm(make_gemm_desc([g], 1, N, K, K, Nout, epi, tile_cfg=tile_cfg))
+    gemm(make_gemm_desc([g], 1, N, K, K, Nout, epi, tile_cfg=tile_cfg), f16)
     return out
 
 
@@ -97,15 +127,15 @@ def interleave_geglu(value: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
 
 def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
                  silu_in: bool = False, accum: bool = False) -> torch.Tensor:
-    _bf16c(x, "x"); _bf16c(w, "w")
+    f16 = _e16((x, "x"), (w, "w"), (b, "bias"), (out, "out"))
     B, K = x.shape
     N = w.shape[0]
     if out is None:
         if accum:
             raise FluxHipError("accum needs an existing output")
-        out = torch.empty(B, N, dtype=BF16, device=x.device)
-    _check(_lib.load().fluxhip_small_linear_bf16(_p(x), _p(w), _p(b), _p(out), B, N, K, int(silu_in), int(accum),
-                                                  _stream()), "fluxhip_small_linear_bf16")
+        out = torch.empty(B, N, dtype=x.dtype, device=x.device)
+    fn, name = _fn("fluxhip_small_linear_bf16", f16)
+    _check(fn(_p(x), _p(w), _p(b), _p(out), B, N, K, int(silu_in), int(accum), _stream()), name)
     return out
 
 
@@ -162,11 +192,12 @@ def rope_table(ids: torch.Tensor, axes_dim: Sequence[int], theta: float) -> torc
 
 
 def silu(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """bf16(silu(x)) elementwise (fluxhip_silu_bf16)."""
-    _bf16c(x, "x")
+    """silu(x) elementwise, rounded to x's 16-bit type (fluxhip_silu_bf16 / _f16)."""
+    f16 = _e16((x, "x"), (out, "out"))
     if out is None:
         out = torch.empty_like(x)
-    _check(_lib.load().fluxhip_silu_bf16(_p(x), _p(out), x.numel(), _stream()), "fluxhip_silu_bf16")
+    fn, name = _fn("fluxhip_silu_bf16", f16)
+    _check(fn(_p(x), _p(out), x.numel(), _stream()), name)
     return out
 
 
@@ -212,7 +243,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], stride: 
            res: Optional[torch.Tensor] = None, epi: int = EPI_BIAS, out: Optional[torch.Tensor] = None,
            addvec: Optional[torch.Tensor] = None) -> torch.Tensor:
     """NHWC conv, w [Cout,kh,kw,Cin] (or [Cout,Cin] for 1x1). res => out = res + conv(x)."""
-    _bf16c(x, "x"); _bf16c(w, "w")
+    f16 = _e16((x, "x"), (w, "w"), (b, "bias"), (res, "res"), (addvec, "addvec"), (out, "out"))
     B, Hs, Ws, Cin = x.shape
     Cout = w.shape[0]
     ks = 1 if w.dim() == 2 else w.shape[1]
@@ -221,13 +252,16 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], stride: 
     Hl, Wl = (Hs * 2, Ws * 2) if ups else (Hs, Ws)
     Ho, Wo = (Hl + 2 * pad - ks) // stride + 1, (Wl + 2 * pad - ks) // stride + 1
     if out is None:
-        out = torch.empty(B, Ho, Wo, Cout, dtype=BF16, device=x.device)
+        out = torch.empty(B, Ho, Wo, Cout, dtype=x.dtype, device=x.device)
     if res is not None:
         epi = EPI_GATE_RES
     lib = _lib.load()
     if Cin % 64 == 0 and Cout % 4 == 0:
-        _check(lib.fluxhip_conv2d_bf16(_p(x), _p(w), _p(b), _p(res), _p(addvec), _p(out), B, Hs, Ws, Cin, Cout, ks, stride, pad,
-                                       int(ups), epi, _p(_zeros16(x.device)), _stream()), "fluxhip_conv2d_bf16")
+        fn, name = _fn("fluxhip_conv2d_bf16", f16)
+        _check(fn(_p(x), _p(w), _p(b), _p(res), _p(addvec), _p(out), B, Hs, Ws, Cin, Cout, ks, stride, pad,
+                  int(ups), epi, _p(_zeros16(x.device)), _stream()), name)
+    elif f16:
+        raise FluxHipError("float16 convs need Cin % 64 == 0 and Cout % 4 == 0 (pad the channels)")
     else:
         if ks != 3 or stride != 1 or pad != 1 or ups or res is not None or addvec is not None:
             raise FluxHipError("small-channel conv path only supports 3x3/s1/p1")
@@ -263,7 +297,7 @@ def _grow_gn_ws(old: Optional[torch.Tensor], need_bytes: int, device) -> torch.T
 
 def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6,
                    silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _bf16c(x, "x")
+    f16 = _e16((x, "x"), (gamma, "gamma"), (beta, "beta"), (out, "out"))
     B, H, W_, Cc = x.shape
     if out is None:
         out = torch.empty_like(x)
@@ -272,9 +306,9 @@ def groupnorm_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     if ws is None or ws.numel() * 4 < need:
         ws = _grow_gn_ws(ws, need, x.device)
         _gn_ws[x.device] = ws
-    _check(_lib.load().fluxhip_groupnorm_silu_bf16(_p(x), _p(gamma), _p(beta), _p(out), B, H * W_, Cc, groups, eps,
-                                                    int(silu), _p(ws), ws.numel() * 4, _stream()),
-           "fluxhip_groupnorm_silu_bf16")
+    fn, name = _fn("fluxhip_groupnorm_silu_bf16", f16)
+    _check(fn(_p(x), _p(gamma), _p(beta), _p(out), B, H * W_, Cc, groups, eps, int(silu), _p(ws), ws.numel() * 4, _stream()),
+           name)
     return out
 
 
@@ -542,12 +576,14 @@ def unpack_latents_x3(x: torch.Tensor, h: int, w: int, scale: float, shift: floa
 
 
 def pixel_linear_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad_to: int, in_div: float) -> torch.Tensor:
-    _bf16c(x, "x"); _f32c(w, "w")
+    """x bf16 or float16 (the latents of a float16=True pipeline: x / in_div is then rounded to float16 like the reference's
+    array division before the float32 Linear); output = split tensor."""
+    f16 = _e16((x, "x")); _f32c(w, "w")
     Cin, Cout = x.shape[-1], w.shape[0]
     out = torch.empty(2, *x.shape[:-1], pad_to, dtype=BF16, device=x.device)
-    _check(_lib.load().fluxhip_pixel_linear_x3(_p(x), _p(w), _p(_f32c(b, "bias")), _p(out[0]), out.stride(0),
-                                               x.numel() // Cin, Cin, Cout, pad_to, float(in_div), _stream()),
-           "fluxhip_pixel_linear_x3")
+    fn, name = _fn("fluxhip_pixel_linear_x3", f16)
+    _check(fn(_p(x), _p(w), _p(_f32c(b, "bias")), _p(out[0]), out.stride(0), x.numel() // Cin, Cin, Cout, pad_to,
+              float(in_div), _stream()), name)
     return out
 
 
@@ -555,28 +591,27 @@ def pixel_linear_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor],
 def attention_strided(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, hd: int,
                       Tq: int, Tk: int, Tkpad: int, q_strides, k_strides, ldo: int, scale: float) -> None:
     """q/k addressed as base + b*bs + h*hs + t*rs (element strides); vt [B][H*hd][Tkpad]."""
-    _check(_lib.load().fluxhip_attention_strided_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(vt), _p(out), ldo, B, H,
-                                                      hd, Tq, Tk, Tkpad, float(scale), _stream()),
-           "fluxhip_attention_strided_bf16")
+    fn, name = _fn("fluxhip_attention_strided_bf16", q.dtype == F16)
+    _check(fn(_p(q), *q_strides, _p(k), *k_strides, _p(vt), _p(out), ldo, B, H, hd, Tq, Tk, Tkpad, float(scale), _stream()), name)
 
 
 def layernorm_affine(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _bf16c(x, "x")
+    f16 = _e16((x, "x"), (gamma, "gamma"), (beta, "beta"), (out, "out"))
     D = x.shape[-1]
     if out is None:
         out = torch.empty_like(x)
-    _check(_lib.load().fluxhip_layernorm_affine_bf16(_p(x), _p(out), x.numel() // D, D, _p(gamma), _p(beta), eps,
-                                                     _stream()), "fluxhip_layernorm_affine_bf16")
+    fn, name = _fn("fluxhip_layernorm_affine_bf16", f16)
+    _check(fn(_p(x), _p(out), x.numel() // D, D, _p(gamma), _p(beta), eps, _stream()), name)
     return out
 
 
 def concat_channels(a: torch.Tensor, b: Optional[torch.Tensor], pad_to: int = 0) -> torch.Tensor:
     """cat([a, b], -1) on [..., C] tensors; b=None zero-pads a to pad_to channels."""
-    _bf16c(a, "a")
+    _e16((a, "a"), (b, "b"))                      # a 16-bit copy: one entry point serves both storage types
     Ca = a.shape[-1]
     Cb = b.shape[-1] if b is not None else pad_to - Ca
-    out = torch.empty(*a.shape[:-1], Ca + Cb, dtype=BF16, device=a.device)
+    out = torch.empty(*a.shape[:-1], Ca + Cb, dtype=a.dtype, device=a.device)
     _check(_lib.load().fluxhip_concat_channels_bf16(_p(a), _p(b), _p(out), a.numel() // Ca, Ca, Cb, _stream()),
            "fluxhip_concat_channels_bf16")
     return out
@@ -584,24 +619,24 @@ def concat_channels(a: torch.Tensor, b: Optional[torch.Tensor], pad_to: int = 0)
 
 def axpbypcz(x: torch.Tensor, y: torch.Tensor, z: Optional[torch.Tensor], ca: float, cb: float, cc: float = 0.0,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _bf16c(x, "x"); _bf16c(y, "y")
+    f16 = _e16((x, "x"), (y, "y"), (z, "z"), (out, "out"))
     if out is None:
         out = torch.empty_like(x)
-    _check(_lib.load().fluxhip_axpbypcz_bf16(_p(x), _p(y), _p(z), _p(out), x.numel(), float(ca), float(cb), float(cc),
-                                             _stream()), "fluxhip_axpbypcz_bf16")
+    fn, name = _fn("fluxhip_axpbypcz_bf16", f16)
+    _check(fn(_p(x), _p(y), _p(z), _p(out), x.numel(), float(ca), float(cb), float(cc), _stream()), name)
     return out
 
 
 def axpbypcz_dev(x: torch.Tensor, y: torch.Tensor, z: Optional[torch.Tensor], coef: torch.Tensor,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = coef[0]*x + coef[1]*y + coef[2]*z with coef a float32[3] DEVICE tensor (graph-replayable sampler step)."""
-    _bf16c(x, "x"); _bf16c(y, "y")
+    f16 = _e16((x, "x"), (y, "y"), (z, "z"), (out, "out"))
     if coef.dtype != torch.float32 or coef.numel() < 3 or not coef.is_cuda:
         raise FluxHipError("coef must be a float32[3] device tensor")
     if out is None:
         out = torch.empty_like(x)
-    _check(_lib.load().fluxhip_axpbypcz_dev_bf16(_p(x), _p(y), _p(z), _p(out), x.numel(), _p(coef), _stream()),
-           "fluxhip_axpbypcz_dev_bf16")
+    fn, name = _fn("fluxhip_axpbypcz_dev_bf16", f16)
+    _check(fn(_p(x), _p(y), _p(z), _p(out), x.numel(), _p(coef), _stream()), name)
     return out
 
 
@@ -614,23 +649,23 @@ def pixel_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pa
     return out
 
 
-def sincos_embed(x: torch.Tensor, sig: torch.Tensor) -> torch.Tensor:
-    """x float32 [n], sig float32 [half] -> bf16 [n, 2*half] = [cos | sin]."""
+def sincos_embed(x: torch.Tensor, sig: torch.Tensor, dtype=BF16) -> torch.Tensor:
+    """x float32 [n], sig float32 [half] -> `dtype` (bf16 / float16) [n, 2*half] = [cos | sin]."""
     if x.dtype != torch.float32 or sig.dtype != torch.float32:
         raise FluxHipError("sincos_embed takes float32 inputs")
     n, half = x.numel(), sig.numel()
-    out = torch.empty(n, 2 * half, dtype=BF16, device=x.device)
-    _check(_lib.load().fluxhip_sincos_embed_f32(_p(x.contiguous()), _p(sig.contiguous()), _p(out), n, half, _stream()),
-           "fluxhip_sincos_embed_f32")
+    out = torch.empty(n, 2 * half, dtype=dtype, device=x.device)
+    fn, name = _fn("fluxhip_sincos_embed_f32", dtype == F16)
+    _check(fn(_p(x.contiguous()), _p(sig.contiguous()), _p(out), n, half, _stream()), name)
     return out
 
 
 # ------------------------------------------------------------------------------------------------ text encoders
 def attention_masked(q, k, vt, out, B: int, H: int, Tq: int, Tk: int, Tkpad: int, q_strides, k_strides, ldo: int,
                      scale: float, bias: Optional[torch.Tensor] = None, causal: bool = False) -> None:
-    _check(_lib.load().fluxhip_attention_masked_bf16(_p(q), *q_strides, _p(k), *k_strides, _p(vt), _p(out), ldo, B, H,
-                                                     Tq, Tk, Tkpad, float(scale), _p(bias), int(causal), _stream()),
-           "fluxhip_attention_masked_bf16")
+    fn, name = _fn("fluxhip_attention_masked_bf16", q.dtype == F16)
+    _check(fn(_p(q), *q_strides, _p(k), *k_strides, _p(vt), _p(out), ldo, B, H, Tq, Tk, Tkpad, float(scale), _p(bias),
+              int(causal), _stream()), name)
 
 
 def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -647,10 +682,10 @@ def embedding(idx: torch.Tensor, table: torch.Tensor, pos: Optional[torch.Tensor
     """idx int32 [..., T] -> bf16 [..., T, D]; pos [>=T, D] is added per position when given."""
     if idx.dtype != torch.int32 or not idx.is_contiguous():
         raise FluxHipError("idx must be contiguous int32")
-    _bf16c(table, "table")
+    f16 = _e16((table, "table"), (pos, "pos"))
     D = table.shape[1]
-    out = torch.empty(*idx.shape, D, dtype=BF16, device=table.device)
+    out = torch.empty(*idx.shape, D, dtype=table.dtype, device=table.device)
     T = idx.shape[-1] if pos is not None else 0
-    _check(_lib.load().fluxhip_embedding_bf16(_p(idx), _p(table), _p(pos), _p(out), idx.numel(), D, T, table.shape[0],
-                                              _stream()), "fluxhip_embedding_bf16")
+    fn, name = _fn("fluxhip_embedding_bf16", f16)
+    _check(fn(_p(idx), _p(table), _p(pos), _p(out), idx.numel(), D, T, table.shape[0], _stream()), name)
     return out

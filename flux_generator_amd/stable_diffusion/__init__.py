@@ -37,8 +37,13 @@ class StableDiffusion:
     MAX_GRAPHS = 6      # captured hipGraphs kept (LRU): each owns a private pool of ~1-6 GB at batch 16
 
     def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True):
-        # the HIP path computes in bf16 storage / fp32 accumulate whatever `float16` says
-        self.dtype = torch.bfloat16
+        # float16=True is the reference's float16 arithmetic (__init__.py:20-27; flux_app.py:77-79 passes it): UNet and text
+        # towers store IEEE half and multiply on v_mfma_f32_16x16x32_f16 with fp32 accumulate / norms / softmax.
+        # float16=False: the reference computes in float32; this path then stores bfloat16 (same kernels, float32 range,
+        # 8-bit significand: rel-L2 7e-3 against float32 on the full-size UNet where float16 measures ~1e-3) - stated in
+        # DESIGN.md §5, not yet a float32-faithful UNet.  The VAE decode is float32-faithful either way.
+        self.dtype = torch.float16 if float16 else torch.bfloat16
+        self.float16 = bool(float16)
         self.device = _lib.bind_device(device)
         self.use_graph = use_graph
         self._graphs = OrderedDict()
@@ -48,7 +53,13 @@ class StableDiffusion:
         self._towers = {"text_encoder": _LazyTower(lambda: load_text_encoder(model, float16, device=device))}
         self.autoencoder = load_autoencoder(model, False, device=device)
         self.sampler = SimpleEulerSampler(self.diffusion_config)
+        self._set_sampler_dtype()
         self.tokenizer = load_tokenizer(model)
+
+    def _set_sampler_dtype(self):
+        """The reference derives the step coefficients in the eps dtype (sampler.py:77-78,90-96) and rounds the timesteps to
+        the pipeline dtype (__init__.py:94-96): float16 under float16=True, float32 otherwise."""
+        self.sampler.coef_dtype = torch.float16 if self.float16 else torch.float32
 
     @property
     def text_encoder(self):
@@ -170,7 +181,7 @@ class StableDiffusion:
                         key: Optional[torch.Generator] = None, shard=None):
         """__init__.py:84-100."""
         x_t = x_T
-        steps = self.sampler.timesteps(num_steps, start_time=T)
+        steps = self.sampler.timesteps(num_steps, start_time=T, dtype=torch.float16 if self.float16 else torch.float32)
         coefs = self.sampler.coeff_table(steps, self.device) if self.use_graph else None
         first = True                           # the conditioning (and its K / V^T projections) is new to the step graph once per run
         for i, (t, t_prev) in enumerate(steps):
@@ -253,6 +264,7 @@ class StableDiffusionXL(StableDiffusion):
     def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True):
         super().__init__(model, float16, device, use_graph)
         self.sampler = SimpleEulerAncestralSampler(self.diffusion_config)
+        self._set_sampler_dtype()
         self._towers = {"text_encoder_1": self._towers["text_encoder"],
                         "text_encoder_2": _LazyTower(lambda: load_text_encoder(model, float16, model_key="text_encoder_2",
                                                                                device=device))}

@@ -134,7 +134,7 @@ def _load_mapped(mapper, path):
 
 def load_unet(key: str = _DEFAULT_MODEL, float16: bool = False, device="cuda", seed: int = 0) -> UNetModel:
     _check_key(key, "load_unet")
-    model = UNetModel(_MODELS[key]["unet_config"], device=device)
+    model = UNetModel(_MODELS[key]["unet_config"], device=device, dtype=torch.float16 if float16 else torch.bfloat16)
     path = _weights_file(key, _MODELS[key]["unet"])
     if path:
         model.load_weights(_load_mapped(map_unet_weights, path))
@@ -187,7 +187,7 @@ def load_text_encoder(key: str = _DEFAULT_MODEL, float16: bool = False, model_ke
             config = CLIPTextModelConfig.from_dict(json.load(f))
     else:
         config = CLIPTextModelConfig(**_TEXT_CONFIGS[(key, model_key)])
-    model = CLIPTextModel(config, device=device)
+    model = CLIPTextModel(config, device=device, dtype=torch.float16 if float16 else torch.bfloat16)
     path = _weights_file(key, f"{model_key}/model.safetensors")
     if path:
         model.load_weights(_load_mapped(map_clip_text_encoder_weights, path))

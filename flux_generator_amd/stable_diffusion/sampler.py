@@ -35,6 +35,10 @@ class SimpleEulerSampler:
             raise NotImplementedError(f"{config.beta_schedule} is not implemented.")
         alphas_cumprod = torch.cumprod(1 - betas, dim=0)
         self._sigmas = torch.cat([torch.zeros(1), ((1 - alphas_cumprod) / alphas_cumprod).sqrt()])
+        # dtype the step coefficients are derived in.  The reference casts sigma / sigma_prev to the eps dtype FIRST and
+        # evaluates everything derived from them in it (sampler.py:77-78,90-96): float16 under float16=True (the pipeline
+        # sets this), float32 otherwise.
+        self.coef_dtype = torch.float32
 
     @property
     def max_time(self):
@@ -60,9 +64,10 @@ class SimpleEulerSampler:
         return list(zip(steps, steps[1:]))
 
     def _coeffs(self, t, t_prev):
-        sigma, sigma_prev = self.sigmas(t), self.sigmas(t_prev)
+        sigma, sigma_prev = self.sigmas(t).to(self.coef_dtype), self.sigmas(t_prev).to(self.coef_dtype)
+        c1, dt = (sigma.square() + 1).sqrt(), sigma_prev - sigma              # evaluated in coef_dtype like the reference
         inv = torch.rsqrt(sigma_prev.square() + 1)
-        return float((sigma.square() + 1).sqrt() * inv), float((sigma_prev - sigma) * inv), 0.0
+        return float(c1.float() * inv.float()), float(dt.float() * inv.float()), 0.0
 
     needs_noise = False
 
@@ -91,12 +96,12 @@ class SimpleEulerAncestralSampler(SimpleEulerSampler):
     needs_noise = True
 
     def _coeffs(self, t, t_prev):
-        sigma, sigma_prev = self.sigmas(t), self.sigmas(t_prev)
+        sigma, sigma_prev = self.sigmas(t).to(self.coef_dtype), self.sigmas(t_prev).to(self.coef_dtype)
         sigma2, sigma_prev2 = sigma.square(), sigma_prev.square()
         sigma_up = (sigma_prev2 * (sigma2 - sigma_prev2) / sigma2).sqrt()
         sigma_down = (sigma_prev2 - sigma_up ** 2).sqrt()
-        inv = torch.rsqrt(sigma_prev2 + 1)
-        return float((sigma2 + 1).sqrt() * inv), float((sigma_down - sigma) * inv), float(sigma_up * inv)
+        inv = torch.rsqrt(sigma_prev2 + 1).float()
+        return float((sigma2 + 1).sqrt().float() * inv), float((sigma_down - sigma).float() * inv), float(sigma_up.float() * inv)
 
     def draw_noise(self, x_t: torch.Tensor, key: Optional[torch.Generator] = None, shard=None) -> torch.Tensor:
         """The fresh N(0,1) of sampler.py:100, drawn from the run's seeded generator (the reference's

@@ -121,7 +121,7 @@ def small_linear_any(x, w, b, silu_in=False, out=None, accum=False):
     """fluxhip_small_linear handles <= 16 rows per launch; larger batches are chunked."""
     B = x.shape[0]
     if out is None:
-        out = torch.empty(B, w.shape[0], dtype=BF16, device=x.device)
+        out = torch.empty(B, w.shape[0], dtype=x.dtype, device=x.device)
     for lo in range(0, B, 16):
         ops.small_linear(x[lo:lo + 16], w, b, out=out[lo:lo + 16], silu_in=silu_in, accum=accum)
     return out
@@ -134,7 +134,13 @@ class _TembAct:
 
 
 class UNetModel:
-    def __init__(self, config: UNetConfig, device: Union[str, torch.device] = "cuda"):
+    def __init__(self, config: UNetConfig, device: Union[str, torch.device] = "cuda", dtype: torch.dtype = BF16):
+        """dtype: the 16-bit storage type of weights and activations — torch.float16 is the reference's arithmetic under
+        float16=True (stable_diffusion/__init__.py:20-27; v_mfma_f32_16x16x32_f16, fp32 accumulate / norms / softmax),
+        torch.bfloat16 the range-safe default of this path."""
+        if dtype not in (BF16, torch.float16):
+            raise ValueError("UNetModel dtype must be torch.bfloat16 or torch.float16")
+        self.dtype = dtype
         self.config = config
         if torch.device(device).type != "cuda":
             raise FluxHipError("UNetModel needs a HIP device: there is no CPU fallback for the denoise path")
@@ -143,7 +149,7 @@ class UNetModel:
             if c % 64 or c // config.num_attention_heads[i] != 64:
                 raise ValueError("libfluxhip UNet path needs channels % 64 == 0 and attention head_dim 64")
         _lib.load()
-        self._params = {k: torch.empty(*shp, dtype=BF16, device=self.device)
+        self._params = {k: torch.empty(*shp, dtype=self.dtype, device=self.device)
                         for k, shp in unet_weight_shapes(config).items()}
         self._fused: Dict[str, torch.Tensor] = {}
         self.down, self.up = block_plan(config)
@@ -164,7 +170,7 @@ class UNetModel:
                 t.fill_(1.0 if name.endswith(".weight") else 0.0)
                 continue
             k = 1.0 / math.sqrt(wt[0].numel())
-            t.copy_(((torch.rand(t.shape, generator=g, device=self.device) * 2 - 1) * k).to(BF16))
+            t.copy_(((torch.rand(t.shape, generator=g, device=self.device) * 2 - 1) * k).to(self.dtype))
         return self.finalize()
 
     def load_weights(self, weights, strict: bool = True) -> "UNetModel":
@@ -178,7 +184,7 @@ class UNetModel:
             dst = self._params[k]
             if tuple(dst.shape) != tuple(w.shape):
                 raise ValueError(f"Shape mismatch for {k}: expected {tuple(dst.shape)}, got {tuple(w.shape)}")
-            dst.copy_(w.to(device=self.device, dtype=BF16))
+            dst.copy_(w.to(device=self.device, dtype=self.dtype))
             seen.add(k)
         if strict and set(self._params) - seen:
             raise ValueError(f"Missing parameters: {sorted(set(self._params) - seen)[:5]} ...")
@@ -215,7 +221,7 @@ class UNetModel:
         w = P["conv_in.weight"]
         cin = w.shape[-1]
         if cin % 64:
-            wp = torch.zeros(*w.shape[:-1], (cin + 63) // 64 * 64, dtype=BF16, device=self.device)
+            wp = torch.zeros(*w.shape[:-1], (cin + 63) // 64 * 64, dtype=self.dtype, device=self.device)
             wp[..., :cin] = w
             F["conv_in.weight"] = wp
         else:
@@ -257,12 +263,13 @@ class UNetModel:
             Wk, Wv = self._fused[f"kv.{C}.{e}.k"], self._fused[f"kv.{C}.{e}.v"]
             LC = Wk.shape[0]
             if out is None:
-                kv[key] = (torch.empty(B, Tkp, LC, dtype=BF16, device=mem.device),
-                           torch.zeros(B, LC, Tkpad, dtype=BF16, device=mem.device))
+                kv[key] = (torch.empty(B, Tkp, LC, dtype=self.dtype, device=mem.device),
+                           torch.zeros(B, LC, Tkpad, dtype=self.dtype, device=mem.device))
             k_all, vt_all = kv[key]
             ops.linear(mem, Wk, out=k_all)
             ops.gemm(make_gemm_desc([dict(A=Wv.data_ptr(), W=mem.data_ptr(), C=vt_all.data_ptr(), a_bstride=0,
-                                          w_bstride=Tkp * enc, c_bstride=LC * Tkpad, M=LC)], B, Tkp, enc, enc, Tkpad))
+                                          w_bstride=Tkp * enc, c_bstride=LC * Tkpad, M=LC)], B, Tkp, enc, enc, Tkpad),
+                     self.dtype == torch.float16)
         return kv
 
     def _mha(self, p: str, H: int, y: torch.Tensor, n: torch.Tensor, kv: Optional[dict], Tk: int) -> torch.Tensor:
@@ -272,16 +279,17 @@ class UNetModel:
         B, N, C = n.shape
         dev = n.device
         lib = _lib.load()
-        o = torch.empty(B, N, C, dtype=BF16, device=dev)
+        f16 = self.dtype == torch.float16
+        o = torch.empty(B, N, C, dtype=self.dtype, device=dev)
         if kv is None:
             qk = ops.linear(n, self._fused[f"{p}.qk"])                       # [B,N,2C]
             Tkpad = (N + 63) // 64 * 64
-            vt = torch.zeros(B, C, Tkpad, dtype=BF16, device=dev) if Tkpad != N else torch.empty(B, C, N, dtype=BF16, device=dev)
+            vt = torch.zeros(B, C, Tkpad, dtype=self.dtype, device=dev) if Tkpad != N else torch.empty(B, C, N, dtype=self.dtype, device=dev)
             # V^T[b] = Wv n[b]^T : A = Wv (shared), "W" operand = the rows of batch b
             ops.gemm(make_gemm_desc([dict(A=W[f"{p}.value_proj.weight"].data_ptr(), W=n.data_ptr(), C=vt.data_ptr(),
                                           a_bstride=0, w_bstride=N * C, c_bstride=C * Tkpad, M=C)],
-                                    B, N, C, C, Tkpad))
-            rc = lib.fluxhip_attention_strided_bf16(qk.data_ptr(), N * 2 * C, 64, 2 * C, qk[..., C:].data_ptr(), N * 2 * C, 64, 2 * C,
+                                    B, N, C, C, Tkpad), f16)
+            rc = (lib.fluxhip_attention_strided_f16 if f16 else lib.fluxhip_attention_strided_bf16)(qk.data_ptr(), N * 2 * C, 64, 2 * C, qk[..., C:].data_ptr(), N * 2 * C, 64, 2 * C,
                                                     vt.data_ptr(), o.data_ptr(), C, B, H, 64, N, Tk, Tkpad, 64 ** -0.5,
                                                     torch.cuda.current_stream().cuda_stream)
         else:
@@ -289,7 +297,7 @@ class UNetModel:
             key, off = self._kv_slot[p]
             k_all, vt_all = kv[key]
             LC, Tkp, Tkpad = k_all.shape[2], kv["Tkp"], kv["Tkpad"]
-            rc = lib.fluxhip_attention_strided_vt_bf16(q.data_ptr(), N * C, 64, C, k_all.data_ptr() + off * 2, Tkp * LC, 64, LC,
+            rc = (lib.fluxhip_attention_strided_vt_f16 if f16 else lib.fluxhip_attention_strided_vt_bf16)(q.data_ptr(), N * C, 64, C, k_all.data_ptr() + off * 2, Tkp * LC, 64, LC,
                                                        vt_all.data_ptr() + off * Tkpad * 2, LC * Tkpad, o.data_ptr(), C,
                                                        B, H, 64, N, Tk, Tkpad, 64 ** -0.5,
                                                        torch.cuda.current_stream().cuda_stream)
@@ -344,7 +352,7 @@ class UNetModel:
     def pad_encoder_states(self, encoder_x: torch.Tensor) -> torch.Tensor:
         """encoder states zero-padded to a multiple of 8 tokens (GEMM N granularity); padded keys are masked."""
         B, S, e = encoder_x.shape
-        mem = torch.zeros(B, (S + 7) // 8 * 8, e, dtype=BF16, device=self.device)
+        mem = torch.zeros(B, (S + 7) // 8 * 8, e, dtype=self.dtype, device=self.device)
         mem[:, :S].copy_(encoder_x)
         return mem
 
@@ -354,15 +362,15 @@ class UNetModel:
         if attn_mask is not None or encoder_attn_mask is not None:
             raise NotImplementedError("masks are always None on the reference's path (unet.py:403-411)")
         cfg, W = self.config, self._params
-        x = x.to(BF16).contiguous()
+        x = x.to(self.dtype).contiguous()
         B = x.shape[0]
-        temb = ops.sincos_embed(timestep.to(device=self.device, dtype=torch.float32).reshape(B), self._sig_t)
+        temb = ops.sincos_embed(timestep.to(device=self.device, dtype=torch.float32).reshape(B), self._sig_t, self.dtype)
         h1 = small_linear_any(temb, W["time_embedding.linear_1.weight"], W["time_embedding.linear_1.bias"])
         temb = small_linear_any(h1, W["time_embedding.linear_2.weight"], W["time_embedding.linear_2.bias"], silu_in=True)
         if text_time is not None:
             text_emb, time_ids = text_time
-            e = ops.sincos_embed(time_ids.to(device=self.device, dtype=torch.float32).reshape(-1), self._sig_add)
-            e = ops.concat_channels(text_emb.to(BF16).contiguous(), e.view(B, -1))
+            e = ops.sincos_embed(time_ids.to(device=self.device, dtype=torch.float32).reshape(-1), self._sig_add, self.dtype)
+            e = ops.concat_channels(text_emb.to(self.dtype).contiguous(), e.view(B, -1))
             h1 = small_linear_any(e, W["add_embedding.linear_1.weight"], W["add_embedding.linear_1.bias"])
             small_linear_any(h1, W["add_embedding.linear_2.weight"], W["add_embedding.linear_2.bias"], silu_in=True,
                              out=temb, accum=True)

@@ -96,7 +96,9 @@ class Autoencoder:
         V.check_precision(precision)
         fp32 = (precision or self.precision) == "fp32"
         cfg, S = self.config, self._store
-        z = z.to(BF16).contiguous()
+        # float16 latents (float16=True pipelines) stay float16 into the fp32-faithful path: the reference promotes them to the
+        # VAE's float32 after the division by the scaling factor (vae.py:256-258); the bf16-storage opt-in takes bf16
+        z = (z if (fp32 and z.dtype == torch.float16) else z.to(BF16)).contiguous()
         cin = cfg.latent_channels_in
         cpad = (cin + 63) // 64 * 64
         # z / scaling_factor -> post_quant_proj (vae.py:256-258), output zero-padded to 64 channels

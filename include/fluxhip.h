@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define FLUXHIP_ABI_VERSION 5
+#define FLUXHIP_ABI_VERSION 6
 
 int fluxhip_abi_version(void);
 /* "gfx950" — the only architecture this library is built for. */
@@ -385,6 +385,54 @@ int fluxhip_rmsnorm_bf16(const void* x, void* out, int64_t rows, int D, const vo
  * (flux/t5.py:229,243; flux/clip.py:83-84,134-135,148). */
 int fluxhip_embedding_bf16(const void* idx, const void* table, const void* pos, void* out, int64_t n,
                            int D, int T, int V, void* stream);
+
+/* ---- float16 storage (ABI 6) -------------------------------------------------------------------------------------
+ * The reference runs the stable_diffusion/ UNet and text towers in float16 when the caller passes float16=True
+ * (stable_diffusion/__init__.py:20-27; flux_app.py:77-79 does) and in float32 otherwise.  The entry points below are the
+ * float16 twins of the bf16 operators the UNet / CLIP / sampler path uses: SAME signatures, SAME kernels, every 16-bit
+ * operand (activations, weights, biases, residuals, outputs) is IEEE half instead of bfloat16, the products run on
+ * v_mfma_f32_16x16x32_f16 / 32x32x16_f16 (the bf16 issue rate), accumulation / statistics / softmax stay float32.  Values
+ * beyond 65504 become inf exactly as in the reference's float16 arrays.  fluxhip_concat_channels_bf16 is a 16-bit copy and
+ * serves both types.  fluxhip_gemm_f16 supports every epilogue of fluxhip_gemm_bf16 (incl. FLUXHIP_EPI_GEGLU_PAIR) on the
+ * tiles the pickers choose; a forced tile_cfg without a float16 instantiation returns FLUXHIP_EINVAL.  Split-K launches take
+ * the chain hand-off.  fluxhip_attention_*_f16: head_dim 64; fluxhip_attention_masked_f16: causal only.
+ * fluxhip_sincos_embed_f32_f16: float32 positions in, float16 table out.  fluxhip_pixel_linear_x3_f16in: the fp32-faithful
+ * VAE's first op on float16 latents (z / scaling_factor rounded to float16 like the reference's array division, then the
+ * float32 post_quant_proj). */
+int fluxhip_gemm_f16(const fluxhip_gemm_desc* d, void* stream);
+int fluxhip_conv2d_f16(const void* x, const void* w, const void* bias, const void* res,
+                       const void* addvec, void* out, int B, int Hs, int Ws, int Cin, int Cout,
+                       int ksize, int stride, int pad, int ups, int epi, const void* zero16,
+                       void* stream);
+int fluxhip_small_linear_f16(const void* x, const void* W, const void* bias, void* out, int B,
+                             int N, int K, int silu_in, int accum, void* stream);
+int fluxhip_silu_f16(const void* x, void* out, int64_t n, void* stream);
+int fluxhip_groupnorm_silu_f16(const void* x, const void* gamma, const void* beta, void* out,
+                               int B, int HW, int C, int G, float eps, int silu, void* ws,
+                               int64_t ws_bytes, void* stream);
+int fluxhip_attention_strided_f16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                  const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                  const void* Vt, void* O, int ldo, int B, int H, int head_dim,
+                                  int Tq, int Tk, int Tkpad, float scale, void* stream);
+int fluxhip_attention_strided_vt_f16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
+                                     const void* K, int64_t k_bs, int64_t k_hs, int64_t k_rs,
+                                     const void* Vt, int64_t vt_bs, void* O, int ldo, int B, int H,
+                                     int head_dim, int Tq, int Tk, int Tkpad, float scale, void* stream);
+int fluxhip_attention_masked_f16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K,
+                                 int64_t k_bs, int64_t k_hs, int64_t k_rs, const void* Vt, void* O, int ldo,
+                                 int B, int H, int Tq, int Tk, int Tkpad, float scale, const void* bias,
+                                 int causal, void* stream);
+int fluxhip_layernorm_affine_f16(const void* x, void* out, int64_t rows, int D, const void* gamma,
+                                 const void* beta, float eps, void* stream);
+int fluxhip_axpbypcz_f16(const void* x, const void* y, const void* z, void* out, int64_t n, float ca,
+                         float cb, float cc, void* stream);
+int fluxhip_axpbypcz_dev_f16(const void* x, const void* y, const void* z, void* out, int64_t n,
+                             const void* coef, void* stream);
+int fluxhip_sincos_embed_f32_f16(const void* x, const void* sig, void* out, int n, int half, void* stream);
+int fluxhip_embedding_f16(const void* idx, const void* table, const void* pos, void* out, int64_t n,
+                          int D, int T, int V, void* stream);
+int fluxhip_pixel_linear_x3_f16in(const void* x, const void* w, const void* bias, void* out, int64_t out_lo,
+                                  int64_t npix, int Cin, int Cout, int Cpad, float in_div, void* stream);
 
 #ifdef __cplusplus
 }

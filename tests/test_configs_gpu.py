@@ -216,60 +216,70 @@ def _sdxl_cfg(**over):
     return kw
 
 
-def _subset_model(dev, kw, prefixes, seed):
+def _subset_model(dev, kw, prefixes, seed, dtype=BF):
     """UNetModel with only the parameters under `prefixes` loaded (the rest stay unallocated garbage and are not
     touched by the block under test), plus the fp32 oracle weights of those parameters."""
     from flux_generator_amd.stable_diffusion.config import UNetConfig
     from flux_generator_amd.stable_diffusion.unet import UNetModel
     ocfg = S.UNetConfig(**kw)
     shapes = {k: v for k, v in S.unet_weight_shapes(ocfg).items() if k.startswith(prefixes)}
-    W = {k: v.to(BF).float() for k, v in O.init_weights(shapes, seed=seed, norm_jitter=0.2).items()}
-    model = UNetModel(UNetConfig(**kw), device=dev).load_weights(W, strict=False)
+    W = {k: v.to(dtype).float() for k, v in O.init_weights(shapes, seed=seed, norm_jitter=0.2).items()}
+    model = UNetModel(UNetConfig(**kw), device=dev, dtype=dtype).load_weights(W, strict=False)
     return ocfg, W, model
 
 
+HF = torch.float16
+# (storage type, bound of a full-width block vs the fp32 oracle, bound of the full-size UNet): float16 = the reference's
+# arithmetic under float16=True (11-bit significand), bfloat16 = this path's float16=False storage (8 bits)
+SD_DTYPES = [pytest.param(BF, 1e-2, 2e-2, id="bf16"), pytest.param(HF, 1.5e-3, 2e-3, id="f16")]
+
+
+@pytest.mark.parametrize("dtype,tol,_", SD_DTYPES)
 @pytest.mark.parametrize("hw", [(16, 16), (32, 32)])      # 256 tokens (512 x 512 images) and 1024 tokens
-def test_sdxl_full_width_transformer(dev, hw):
+def test_sdxl_full_width_transformer(dev, hw, dtype, tol, _):
     """Transformer2D at SDXL's deepest width: 1280 channels = 20 heads x 64, cross-attention over 77 text tokens of
     width 2048, GEGLU 1280 -> 2 x 5120 -> 1280 (stable_diffusion/.../unet.py:35-124)."""
     kw = _sdxl_cfg(transformer_layers_per_block=(1, 2, 2))
-    ocfg, W, model = _subset_model(dev, kw, ("mid_blocks.1.",), seed=11)
+    ocfg, W, model = _subset_model(dev, kw, ("mid_blocks.1.",), seed=11, dtype=dtype)
     B = 2
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(B, *hw, 1280, generator=g).to(BF)
-    enc = torch.randn(B, 77, 2048, generator=g).to(BF)
+    x = torch.randn(B, *hw, 1280, generator=g).to(dtype)
+    enc = torch.randn(B, 77, 2048, generator=g).to(dtype)
     ref = S.transformer_2d(W, "mid_blocks.1", 20, 2, x.float(), enc.float())
-    mem = torch.zeros(B, 80, 2048, dtype=BF, device=dev)
+    mem = torch.zeros(B, 80, 2048, dtype=dtype, device=dev)
     mem[:, :77] = enc.to(dev)
     got = model._transformer("mid_blocks.1", 20, 2, x.to(dev), model.text_kv(mem), 77)
     e = rel_l2(got, ref)
-    print(f"sdxl transformer {hw}: rel-L2 {e:.2e}")
-    assert got.shape == ref.shape and e < 1e-2
+    print(f"sdxl transformer {hw} {dtype}: rel-L2 {e:.2e}")
+    assert got.dtype == dtype and got.shape == ref.shape and e < tol
 
 
-def test_sdxl_resnet_320_640_and_downsample(dev):
+@pytest.mark.parametrize("dtype,tol,_", SD_DTYPES)
+def test_sdxl_resnet_320_640_and_downsample(dev, dtype, tol, _):
     """down_blocks.0 (2 x ResnetBlock2D 320 -> 320 at 64 x 64 + stride-2 downsample) feeding the first resnet of
     down_blocks.1 (320 -> 640 with the 1x1 conv_shortcut, + temb) — stable_diffusion/.../unet.py:127-170,227-229."""
     kw = _sdxl_cfg()
     pre = ("down_blocks.0.", "down_blocks.1.resnets.0.")
-    ocfg, W, model = _subset_model(dev, kw, pre, seed=12)
+    ocfg, W, model = _subset_model(dev, kw, pre, seed=12, dtype=dtype)
     B = 2
     g = torch.Generator().manual_seed(6)
-    x = torch.randn(B, 64, 64, 320, generator=g).to(BF)
-    temb = torch.randn(B, 1280, generator=g).to(BF)
+    x = torch.randn(B, 64, 64, 320, generator=g).to(dtype)
+    temb = torch.randn(B, 1280, generator=g).to(dtype)
     down, _ = S._block_plan(ocfg)
     xr, outs = S.unet_block(W, "down_blocks.0", down[0], x.float(), None, temb.float())
     ref = S.resnet_block_2d(W, "down_blocks.1.resnets.0", xr, temb.float())
     xg, gouts = model._block(model.down[0], x.to(dev), None, 0, temb.to(dev), None)
     assert len(gouts) == len(outs) == 3 and xg.shape == (B, 32, 32, 320)
     for a, b in zip(gouts, outs):
-        assert rel_l2(a, b) < 1e-2
+        assert rel_l2(a, b) < tol
     got = model._resnet("down_blocks.1.resnets.0", xg, temb.to(dev))
-    assert got.shape == (B, 32, 32, 640) and rel_l2(got, ref) < 1e-2
+    assert got.shape == (B, 32, 32, 640) and rel_l2(got, ref) < tol
 
 
-def test_sdxl_full_size_unet(dev):
-    """The full-size SDXL UNet (2.567 B parameters) at BASELINE.json configs[3]'s shape: batch 16, 64 x 64 latents,
+@pytest.mark.parametrize("dtype,_,tol", SD_DTYPES)
+def test_sdxl_full_size_unet(dev, dtype, _, tol):
+    """(float16: the reference's arithmetic under float16=True, bound 2e-3; bfloat16: 2e-2, measured 7.0e-3.)
+    The full-size SDXL UNet (2.567 B parameters) at BASELINE.json configs[3]'s shape: batch 16, 64 x 64 latents,
     77 x 2048 text states, text_time conditioning.
       1. repeatable bit for bit; 2. hipGraph replay == eager; 3. batch consistency (16 copies of one image ==
       the batch-1 result, to bf16 tolerance: tile picks differ with M); 4. batch-1 PARITY with the fp32 oracle at
@@ -277,13 +287,13 @@ def test_sdxl_full_size_unet(dev):
     from flux_generator_amd.stable_diffusion.config import UNetConfig
     from flux_generator_amd.stable_diffusion.unet import UNetModel
     kw = _sdxl_cfg()
-    model = UNetModel(UNetConfig(**kw), device=dev).init_random(5)
+    model = UNetModel(UNetConfig(**kw), device=dev, dtype=dtype).init_random(5)
     nparam = sum(v.numel() for v in model.parameters().values())
     assert abs(nparam / 1e9 - 2.567) < 0.01
     g = torch.Generator().manual_seed(9)
-    x1 = (torch.randn(1, 64, 64, 4, generator=g) * 0.9977).to(BF)
-    enc1 = torch.randn(1, 77, 2048, generator=g).to(BF)
-    pooled1 = torch.randn(1, 1280, generator=g).to(BF)
+    x1 = (torch.randn(1, 64, 64, 4, generator=g) * 0.9977).to(dtype)
+    enc1 = torch.randn(1, 77, 2048, generator=g).to(dtype)
+    pooled1 = torch.randn(1, 1280, generator=g).to(dtype)
     tid1 = torch.tensor([[512, 512, 0, 0, 512, 512.0]])
     t1 = torch.tensor([999.0])
 
@@ -298,7 +308,7 @@ def test_sdxl_full_size_unet(dev):
     for i in range(1, 16):
         assert torch.equal(a[0], a[i]), f"image {i} of identical inputs differs"
     one = run(1)
-    assert rel_l2(a[:1], one.float().cpu()) < 1.5e-2
+    assert rel_l2(a[:1], one.float().cpu()) < (1.5e-2 if dtype == BF else 2e-3)
 
     sx, st, se = x1.repeat(16, 1, 1, 1).to(dev), t1.repeat(16).to(dev), enc1.repeat(16, 1, 1).to(dev)
     stt = (pooled1.repeat(16, 1).to(dev), tid1.repeat(16, 1).to(dev))
@@ -321,8 +331,8 @@ def test_sdxl_full_size_unet(dev):
     with torch.no_grad():
         ref = S.unet_forward(ocfg, Wc, x1.float(), t1, enc1.float(), (pooled1.float(), tid1))
     e = rel_l2(one, ref)
-    print(f"full-size SDXL UNet batch-1 rel-L2 vs fp32 oracle: {e:.2e}")
-    assert e < 2e-2
+    print(f"full-size SDXL UNet batch-1 {dtype} rel-L2 vs fp32 oracle: {e:.2e}")
+    assert e < tol
 
 
 # ------------------------------------------------------------------------------------------ multi-GPU path on one GPU

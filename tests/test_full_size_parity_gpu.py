@@ -3,23 +3,30 @@ configs[1]: Flux-schnell, 19 double + 38 single blocks, width 3072, 512 x 512 ->
 
 Everything else in tests/ compares depth <= 2 + 3 models (or single full-width blocks) with the oracle and checks the
 57-block model through properties; here the whole model runs on both sides, so the compounding of the bf16-storage
-rounding through 57 gated residual blocks at width 3072 is MEASURED:
+rounding through 57 gated residual blocks at width 3072 is MEASURED (round 4, profiles/r04_parity_full_size.json):
 
-  a1  one forward (t = 1.0)                                              rel-L2(pred)     <= 1e-2   vs the fp32 oracle
-  a2  the 2-step schnell loop through FluxPipeline._denoising_loop
-      (hipGraph replay + hoisted modulation tables, i.e. the product's own loop)   rel-L2(latents) <= 2e-2   vs the fp32 oracle loop
-  a3  decode of the final latents (fp32-faithful VAE, 64 x 64 x 16 -> 512 x 512 x 3)
-      vs oracle.pipeline_decode on the SAME latents                      max-abs          <= 1/255
-  a4  the same forward in the oracle's bf16 mode (= the reference's own arithmetic: MLX rounds every op's output to
-      bf16, flux/flux.py:24) — the HIP path must be no further from fp32 than the reference's arithmetic is (x 1.5)
-  b   `enable_fp8()` forward vs the fp32 oracle on the DE-QUANTISED weights  rel-L2(pred)  <= 6e-2
-  c   the same with every modulation bias drawn from U(-0.5, 0.5) (gates / shifts / scales of O(0.3), where the default
-      init leaves them at O(0.03) and every block close to the identity): the residual stream then really is rewritten
-      57 times                                                             rel-L2(pred)  <= 2e-2
-  d   FLUXHIP_FULL_ORACLE=1: Flux-dev 1024 x 1024 (T = 4608, guidance embedding), one forward   <= 1e-2
+  a1  one forward (t = 1.0) against the oracle in bf16 mode = the REFERENCE'S OWN ARITHMETIC (the MLX pipeline is bf16,
+      flux/flux.py:24: every op returns a bf16 array)                     rel-L2(pred)   <= 1e-2    measured 5.2e-3
+      ... and against the fp32 oracle: no further from it than the reference's arithmetic is
+          rel-L2(HIP, fp32) <= 1.1 x rel-L2(bf16 oracle, fp32) + 5e-4, and <= 2e-2          measured 1.415e-2 vs 1.416e-2
+      What this says: at depth 57 BOTH bf16 pipelines sit 1.4e-2 from the fp32 answer and 5e-3 from each other — most
+      of the distance is the bf16 rounding of the residual stream, which two implementations that agree to < 1 ulp
+      round the SAME way (test_c2_which_rounding_compounds isolates it).  An fp32 residual stream would move the HIP path
+      towards the fp32 oracle and AWAY from what the reference computes, so it is not what the path does.
+  a2  the 2-step schnell loop through FluxPipeline._denoising_loop (hipGraph replay + hoisted modulation tables, i.e. the
+      product's own loop) against the fp32 oracle loop                     rel-L2(latents) <= 2e-2  measured 5.7e-3
+  a3  decode of the final latents (fp32-faithful VAE, 64 x 64 x 16 -> 512 x 512 x 3) against oracle.pipeline_decode on
+      the SAME latents                                                     max-abs <= 1/255         measured 2.5e-5
+      (end to end against the all-fp32-oracle image: max-abs 1.1e-2, mean-abs 1.2e-3 — reported, not asserted)
+  b   `enable_fp8()` forward vs the fp32 oracle on the DE-QUANTISED weights   rel-L2(pred) <= 6e-2
+  c   the same forward with every modulation bias drawn from U(-0.5, 0.5) (gates / shifts / scales of O(0.3), where the
+      default init leaves them at O(0.03) and every block close to the identity): the residual stream then really is
+      rewritten 57 times; same two bounds as a1
+  d   FLUXHIP_FULL_ORACLE=1: Flux-dev 1024 x 1024 (T = 4608, guidance embedding), one forward, bounds of a1; and
+      test_c2_which_rounding_compounds (fp32 oracle with ONLY the residual stream rounded to bf16 between blocks)
 
 Both sides use the SAME weights: drawn on the GPU (`init_random`, bf16-representable), fetched to the host one tensor
-at a time as float32 while the oracle walks the blocks (`DeviceWeights`), so only one block's fp32 weights are resident
+at a time while the oracle walks the blocks (`DeviceWeights`), so only one block's fp32 weights are resident
 on the host.  References: flux/model.py:99-136, flux/flux.py:87-126,157-162, flux/sampler.py:22-31,56-57.
 The measured numbers are written to gpurun_out/parity_full_size.json (committed copy: profiles/r04_parity_full_size.json).
 """
@@ -41,9 +48,12 @@ RESULTS = {}
 
 
 class DeviceWeights(Mapping):
-    """The oracle's weight dict, backed by the HIP model's own device tensors: a key is copied to the host as float32
-    when the oracle asks for it and dropped when the oracle is done with it.  `dequant`: name -> (e4m3 rows, scale) for the
-    layers whose fp8 copy is what the HIP path multiplies with."""
+    """The oracle's weight dict, backed by the HIP model's own device tensors: a key is converted on the GPU and copied
+    into a pinned host staging buffer when the oracle asks for it (two buffers per shape, used alternately: every oracle
+    op consumes its weight before the next one of that shape is requested), so one block's weights are resident at a time
+    and nothing is page-faulted per fetch.  `dequant`: name -> (e4m3 rows, scale) for the layers whose fp8 copy is what
+    the HIP path multiplies with."""
+    _stage = {}
 
     def __init__(self, params, dequant=None, dtype=torch.float32):
         self.p, self.dq, self.dtype = params, dequant or {}, dtype
@@ -52,8 +62,15 @@ class DeviceWeights(Mapping):
         base = k[: -len(".weight")] if k.endswith(".weight") else None
         if base in self.dq:
             q, sc = self.dq[base]
-            return (q.view(torch.float8_e4m3fn).float() * sc.float()[:, None]).cpu().to(self.dtype)
-        return self.p[k].float().cpu().to(self.dtype)
+            src = (q.view(torch.float8_e4m3fn).float() * sc.float()[:, None]).to(self.dtype)
+        else:
+            src = self.p[k].to(self.dtype)
+        key = (tuple(src.shape), self.dtype)
+        slot = DeviceWeights._stage.setdefault(key, [0, [torch.empty(src.shape, dtype=self.dtype, pin_memory=True) for _ in range(2)]])
+        slot[0] ^= 1
+        buf = slot[1][slot[0]]
+        buf.copy_(src)
+        return buf
 
     def __iter__(self):
         return iter(self.p)
@@ -83,7 +100,6 @@ def _inputs(P, S, lat, seed=11):
 def schnell(dev):
     """The bench's own model: FluxPipeline('flux-schnell') with the seed-0 random init (no checkpoint in this image)."""
     from flux_generator_amd.flux import FluxPipeline
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         pipe = FluxPipeline("flux-schnell")
@@ -162,11 +178,12 @@ def test_c2_full_depth_forward_loop_decode(dev, schnell):
     RESULTS["c2_image_mean_abs_end_to_end"] = m_e2e
     _save()
 
+    schnell["ref0"] = ref0
     assert image.shape == (1, 512, 512, 3)
-    assert e_fwd <= 1e-2, "full-depth forward"
+    assert e_hip16 <= 1e-2, "full-depth forward vs the reference's (bf16) arithmetic"
+    assert e_fwd <= 1.1 * e_ref16 + 5e-4 and e_fwd <= 2e-2, "HIP path is further from fp32 than the reference's bf16 arithmetic"
     assert e_x1 <= 2e-2 and e_x2 <= 2e-2, "2-step loop"
     assert d_img <= 1.0 / 255, "decode of identical latents"
-    assert e_fwd <= 1.5 * e_ref16 + 1e-3, "HIP path is further from fp32 than the reference's bf16 arithmetic"
 
 
 def test_c2_full_depth_live_modulation(dev, schnell):
@@ -182,13 +199,15 @@ def test_c2_full_depth_live_modulation(dev, schnell):
         got = flow(d[0], d[1], d[2], d[3], torch.full((1,), 0.5, dtype=BF, device=dev), d[4])
         ref, secs = _oracle_forward(OP, DeviceWeights(flow.parameters()), inputs, 0.5)
         ref16, _ = _oracle_forward(OP, DeviceWeights(flow.parameters(), dtype=BF), inputs, 0.5, dtype=BF)
-        e, e16 = rel_l2(got, ref), rel_l2(ref16, ref)
-        print(f"[c] live modulation (bias U(-0.5,0.5)): HIP vs fp32 oracle {e:.3e}; bf16 oracle vs fp32 {e16:.3e}  ({secs:.0f} s)")
+        e, e16, eh = rel_l2(got, ref), rel_l2(ref16, ref), rel_l2(got, ref16)
+        print(f"[c] live modulation (bias U(-0.5,0.5)): HIP vs bf16 oracle {eh:.3e}; HIP vs fp32 oracle {e:.3e}; "
+              f"bf16 oracle vs fp32 {e16:.3e}  ({secs:.0f} s)")
+        RESULTS["c2_live_modulation_rel_l2_vs_bf16_oracle"] = eh
         RESULTS["c2_live_modulation_rel_l2_vs_fp32"] = e
         RESULTS["c2_live_modulation_bf16_oracle_vs_fp32"] = e16
         _save()
-        assert e <= 2e-2
-        assert e <= 1.5 * e16 + 1e-3
+        assert eh <= 1e-2
+        assert e <= 1.1 * e16 + 5e-4 and e <= 2e-2
     finally:
         flow.mod_b.copy_(keep)
 
@@ -213,6 +232,39 @@ def test_c2_full_depth_fp8_forward(dev, schnell):
         flow.enable_fp8(False)
 
 
+@pytest.mark.skipif(os.environ.get("FLUXHIP_FULL_ORACLE") != "1", reason="FLUXHIP_FULL_ORACLE=1: one more oracle forward")
+def test_c2_which_rounding_compounds(dev, schnell):
+    """Which rounding carries the 1.4e-2 between a bf16 pipeline and the fp32 answer at depth 57?  The fp32 oracle with
+    ONE change — the residual stream (img / txt, then the joint x) rounded to bf16 after every block, everything inside a
+    block still float32 — against the plain fp32 oracle.  (The real pipelines round the stream twice per double block and
+    every op output besides, so this is a lower bound of the stream's share.)"""
+    pipe, OP, inputs = schnell["pipe"], schnell["OP"], schnell["inputs"]
+    if "ref0" not in schnell:
+        pytest.skip("needs test_c2_full_depth_forward_loop_decode's fp32 reference")
+    W = DeviceWeights(pipe.flow.parameters())
+    img, img_ids, txt, txt_ids, y = inputs
+    rb = lambda x: x.to(BF).float()      # noqa: E731
+    with torch.no_grad():
+        tt = torch.full((1,), 1.0, dtype=BF)
+        x_img = O.linear(img.float(), W["img_in.weight"], W["img_in.bias"])
+        vec = O.mlp_embedder(W, "time_in", O.timestep_embedding(tt, 256).float()) + O.mlp_embedder(W, "vector_in", y.float())
+        x_txt = O.linear(txt.float(), W["txt_in.weight"], W["txt_in.bias"])
+        pe = O.embed_nd(torch.cat([txt_ids, img_ids], dim=1), OP.axes_dim, OP.theta).to(BF).float()
+        x_img, x_txt = rb(x_img), rb(x_txt)
+        for i in range(OP.depth):
+            x_img, x_txt = O.double_stream_block(W, f"double_blocks.{i}", OP.num_heads, x_img, x_txt, vec, pe)
+            x_img, x_txt = rb(x_img), rb(x_txt)
+        x = torch.cat([x_txt, x_img], dim=1)
+        for i in range(OP.depth_single_blocks):
+            x = rb(O.single_stream_block(W, f"single_blocks.{i}", OP.num_heads, x, vec, pe))
+        out = O.last_layer(W, x[:, x_txt.shape[1]:], vec)
+    e = rel_l2(out, schnell["ref0"])
+    print(f"[d] fp32 oracle with only the residual stream rounded to bf16 between blocks vs plain fp32: {e:.3e}")
+    RESULTS["c2_fp32_oracle_stream_rounded_vs_fp32"] = e
+    _save()
+    assert 1e-3 < e < 2e-2
+
+
 @pytest.mark.skipif(os.environ.get("FLUXHIP_FULL_ORACLE") != "1", reason="FLUXHIP_FULL_ORACLE=1: ~10 min of host time")
 def test_c3_full_depth_dev_1024_forward(dev):
     """d: Flux-dev at BASELINE.json configs[2]'s shape (S = 512, L = 4096, T = 4608, guidance 7), one forward."""
@@ -227,8 +279,12 @@ def test_c3_full_depth_dev_1024_forward(dev):
     got = flow(d[0], d[1], d[2], d[3], torch.full((1,), ts[1], dtype=BF, device=dev), d[4],
                torch.full((1,), 7.0, dtype=BF, device=dev))
     ref, secs = _oracle_forward(OP, DeviceWeights(flow.parameters()), inputs, ts[1], guidance=7.0)
-    e = rel_l2(got, ref)
-    print(f"[d] Flux-dev T=4608 full-depth forward vs fp32 oracle: {e:.3e}  ({secs:.0f} s)")
+    ref16, _ = _oracle_forward(OP, DeviceWeights(flow.parameters(), dtype=BF), inputs, ts[1], guidance=7.0, dtype=BF)
+    e, e16, eh = rel_l2(got, ref), rel_l2(ref16, ref), rel_l2(got, ref16)
+    print(f"[d] Flux-dev T=4608 full-depth forward: HIP vs bf16 oracle {eh:.3e}; HIP vs fp32 {e:.3e}; bf16 oracle vs fp32 {e16:.3e}  ({secs:.0f} s)")
+    RESULTS["c3_dev1024_forward_rel_l2_vs_bf16_oracle"] = eh
     RESULTS["c3_dev1024_forward_rel_l2_vs_fp32"] = e
+    RESULTS["c3_dev1024_bf16_oracle_vs_fp32"] = e16
     _save()
-    assert e <= 1e-2
+    assert eh <= 1e-2
+    assert e <= 1.1 * e16 + 5e-4 and e <= 2e-2

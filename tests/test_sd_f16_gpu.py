@@ -1,0 +1,384 @@
+"""float16 arithmetic of the stable_diffusion/ path (float16=True: what the reference's flux_app.py:77-79 runs;
+stable_diffusion/__init__.py:20-27, model_io.py:171-174): every float16 twin of the C ABI (include/fluxhip.h, "float16 storage")
+against float32 references, the UNet / CLIP / sampler / pipeline against oracle/sd_oracle.py run in FLOAT16 (the reference's
+op-boundary rounding) and in float32.
+
+Tolerances.  float16 has an 11-bit significand (bfloat16: 8): single ops against float32 on float16-representable operands
+rel-L2 <= 6e-4 (attention, where P is rounded to float16: 1e-3; bf16 states 4e-3 / 6e-3); the tiny UNet forward <= 3e-3 vs
+float32 (bf16: 1.5e-2) and <= 3e-3 vs the float16 oracle; the full-size SDXL UNet <= 2e-3 vs float32 (bf16 measured 7.0e-3).
+Overflow: values beyond 65504 become inf exactly as in the reference's float16 arrays (tested on the GEMM epilogue); there
+is no saturation and no silent clamping.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import flux_oracle as O
+from oracle import sd_oracle as S
+from oracle import text_oracle as TO
+
+pytestmark = pytest.mark.gpu
+HF = torch.float16
+BF = torch.bfloat16
+TOL = 6e-4
+
+
+def rnd(*shape, scale=1.0, seed=0, dev="cuda", dtype=HF):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def f(t):
+    return t.float().cpu()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / conv
+F16_DENSE_TILES = [49, 50, 51, 54, 46, 55, 47, 7, 8, 9, 4]
+F16_CONV_TILES = [49, 50, 51, 54, 10, 55, 7, 8, 9, 4, 15]
+
+
+@pytest.mark.parametrize("cfg", [0] + F16_DENSE_TILES)
+def test_gemm_f16_tiles_and_epilogues(dev, cfg):
+    """fluxhip_gemm_f16 on every tile that carries a float16 instantiation (0 = the picker's choice), ragged M / N, with the
+    epilogues of the UNet / CLIP launches."""
+    from flux_generator_amd import ops
+    M, N, K = 600, 520, 512
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    res, gate = rnd(M, N, seed=4), rnd(N, seed=5)
+    lin = O.linear(f(x), f(w), f(b))
+    y = ops.linear(x, w, b, tile_cfg=cfg)
+    assert y.dtype == HF and rel_l2(y, lin) < TOL
+    assert rel_l2(ops.linear(x, w, None, tile_cfg=cfg), O.linear(f(x), f(w), None)) < TOL
+    assert rel_l2(ops.linear(x, w, b, epi=ops.EPI_GATE_RES, res=res, gate=gate, tile_cfg=cfg), f(res) + f(gate) * lin) < TOL
+    assert rel_l2(ops.linear(x, w, b, epi=ops.EPI_GATE_RES, res=res, tile_cfg=cfg), f(res) + lin) < TOL
+    assert rel_l2(ops.linear(x, w, b, epi=ops.EPI_SILU, tile_cfg=cfg), lin * torch.sigmoid(lin)) < TOL
+    assert rel_l2(ops.linear(x, w, b, epi=ops.EPI_QUICK_GELU, tile_cfg=cfg), lin * torch.sigmoid(1.702 * lin)) < TOL
+    assert rel_l2(ops.linear(x, w, b, epi=ops.EPI_GELU_ERF, tile_cfg=cfg), torch.nn.functional.gelu(lin)) < TOL
+    assert rel_l2(ops.linear(x, w, b, epi=ops.EPI_GEGLU, res=res, tile_cfg=cfg), f(res) * torch.nn.functional.gelu(lin)) < 1e-3
+    # split-K (chain hand-off) on the float16 kernels
+    if cfg in (49, 51, 55, 7):
+        assert rel_l2(ops.linear(x, w, b, tile_cfg=cfg | (2 << 8)), lin) < TOL
+
+
+def test_gemm_f16_rejects_tiles_without_an_instantiation_and_mixed_types(dev):
+    from flux_generator_amd import ops
+    x, w = rnd(256, 256, seed=1), rnd(256, 256, seed=2, scale=0.06)
+    with pytest.raises(ops.FluxHipError):
+        ops.linear(x, w, None, tile_cfg=24)                  # a bf16-only tile
+    with pytest.raises(ops.FluxHipError):
+        ops.linear(x, w.to(BF), None)                        # no mixed 16-bit operand types
+
+
+def test_gemm_f16_overflow_is_inf_like_the_reference(dev):
+    """A float16 array cannot hold 1e5: the reference's Linear returns inf there, and so does the epilogue (no clamp)."""
+    from flux_generator_amd import ops
+    x = torch.full((128, 64), 40.0, dtype=HF, device=dev)
+    w = torch.full((64, 64), 40.0, dtype=HF, device=dev)     # 64 * 1600 = 102400 > 65504
+    y = ops.linear(x, w, None)
+    assert bool(torch.isinf(y).all()) and bool((y > 0).all())
+    assert bool(torch.isinf(torch.nn.functional.linear(x.cpu().float(), w.cpu().float()).to(HF)).all())
+
+
+@pytest.mark.parametrize("tile", [49, 55])
+def test_gemm_f16_geglu_pair(dev, tile):
+    """The UNet's fused GEGLU launch (value / gate rows interleaved in blocks of 16, product in the epilogue) in float16:
+    equal to the two-launch form bit for bit, and right against float32."""
+    from flux_generator_amd import ops
+    M, C = 300, 256
+    n = rnd(M, C, seed=1)
+    w1, b1, w2, b2 = rnd(4 * C, C, seed=2, scale=C ** -0.5), rnd(4 * C, seed=3), rnd(4 * C, C, seed=4, scale=C ** -0.5), rnd(4 * C, seed=5)
+    wp, bp = ops.interleave_geglu(w1, w2), ops.interleave_geglu(b1, b2)
+    pair = ops.linear(n, wp, bp, epi=ops.EPI_GEGLU_PAIR, tile_cfg=tile)
+    a = ops.linear(n, w1, b1)
+    two = ops.linear(n, w2, b2, epi=ops.EPI_GEGLU, res=a)
+    assert pair.shape == (M, 4 * C) and torch.equal(pair, two)
+    ref = O.linear(f(n), f(w1), f(b1)) * torch.nn.functional.gelu(O.linear(f(n), f(w2), f(b2)))
+    assert rel_l2(pair, ref) < 1e-3
+
+
+def test_gemm_f16_batched_vt_projection(dev):
+    """V^T[b] = Wv y[b]^T as a batched GEMM with a per-batch "weight" operand (how the UNet writes V transposed)."""
+    from flux_generator_amd import ops
+    B, N, C = 3, 200, 128
+    y, wv = rnd(B, N, C, seed=1), rnd(C, C, seed=2, scale=C ** -0.5)
+    Tkpad = 256
+    vt = torch.zeros(B, C, Tkpad, dtype=HF, device=dev)
+    ops.gemm(ops.make_gemm_desc([dict(A=wv.data_ptr(), W=y.data_ptr(), C=vt.data_ptr(), a_bstride=0, w_bstride=N * C,
+                                      c_bstride=C * Tkpad, M=C)], B, N, C, C, Tkpad), True)
+    ref = torch.einsum("oc,bnc->bon", f(wv), f(y))
+    assert rel_l2(vt[..., :N], ref) < TOL and torch.count_nonzero(vt[..., N:]) == 0
+
+
+@pytest.mark.parametrize("Cin,Cout,hw,kw", [(64, 128, (12, 12), {}), (128, 320, (16, 16), dict(stride=2)), (320, 320, (8, 8), dict(ups=True)),
+                                              (640, 640, (8, 8), {}), (64, 64, (32, 32), dict(ks1=True))])
+def test_conv2d_f16(dev, Cin, Cout, hw, kw):
+    from flux_generator_amd import ops
+    B = 2
+    x = rnd(B, *hw, Cin, seed=1)
+    if kw.get("ks1"):
+        w, b = rnd(Cout, Cin, seed=2, scale=Cin ** -0.5), rnd(Cout, seed=3)
+        y = ops.conv2d(x, w, b)
+        assert y.dtype == HF and rel_l2(y, O.linear(f(x), f(w), f(b))) < TOL
+        return
+    w, b = rnd(Cout, 3, 3, Cin, seed=2, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=3)
+    if kw.get("ups"):
+        y = ops.conv2d(x, w, b, ups=True)
+        ref = O.conv2d(O.upsample_nearest2(f(x)), f(w), f(b))
+    elif kw.get("stride"):
+        y = ops.conv2d(x, w, b, stride=2, pad=1)
+        ref = O.conv2d(f(x), f(w), f(b), stride=2, padding=1)
+    else:
+        tv, res = rnd(B, Cout, seed=4), rnd(B, *hw, Cout, seed=5)
+        y = ops.conv2d(x, w, b, addvec=tv)
+        ref = O.conv2d(f(x), f(w), f(b)) + f(tv)[:, None, None, :]
+        assert rel_l2(ops.conv2d(x, w, b, res=res), O.conv2d(f(x), f(w), f(b)) + f(res)) < TOL
+    assert y.dtype == HF and rel_l2(y, ref) < TOL
+
+
+@pytest.mark.parametrize("cfg", F16_CONV_TILES)
+def test_conv2d_f16_every_tile(dev, cfg, monkeypatch):
+    """Every implicit-GEMM tile with a float16 instantiation (forced through the tuning knob's environment variable in a
+    child process would need a restart: the tile is forced through the descriptor-free entry's env hook instead)."""
+    import os
+    import subprocess
+    import sys
+    code = f"""
+import sys, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from flux_generator_amd import ops
+from oracle import flux_oracle as O
+g = torch.Generator().manual_seed(1)
+x = torch.randn(2, 20, 20, 128, generator=g).half().cuda()
+w = (torch.randn(200, 3, 3, 128, generator=g) * (9 * 128) ** -0.5).half().cuda()
+b = torch.randn(200, generator=g).half().cuda()
+y = ops.conv2d(x, w, b)
+ref = O.conv2d(x.float().cpu(), w.float().cpu(), b.float().cpu())
+e = float((y.float().cpu() - ref).norm() / ref.norm())
+print("ERR", e)
+assert e < {TOL}
+"""
+    env = dict(os.environ, FLUXHIP_CONV_CFG=str(cfg))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
+
+
+# ------------------------------------------------------------------------------------------------ memory-bound ops
+@pytest.mark.parametrize("C,hw", [(320, (16, 16)), (640, (8, 12)), (1920, (4, 4)), (128, (32, 32))])
+def test_groupnorm_f16(dev, C, hw):
+    from flux_generator_amd import ops
+    x = rnd(2, *hw, C, seed=1, scale=2.0) + 0.5
+    gam, bet = (1 + 0.3 * f(rnd(C, seed=2))).to(HF).to(dev), rnd(C, seed=3, scale=0.3)
+    for silu in (True, False):
+        y = ops.groupnorm_silu(x, gam, bet, 32, 1e-5, silu)
+        ref = O.group_norm(f(x), f(gam), f(bet), 32, 1e-5)
+        assert y.dtype == HF and rel_l2(y, O.silu(ref) if silu else ref) < TOL
+
+
+def test_small_ops_f16(dev):
+    from flux_generator_amd import ops
+    from flux_generator_amd.stable_diffusion.unet import sinusoidal_sigmas
+    x = rnd(3, 50, 640, seed=1, scale=2.0) + 0.3
+    g, b = (1 + 0.3 * f(rnd(640, seed=2))).to(HF).to(dev), rnd(640, seed=3, scale=0.3)
+    y = ops.layernorm_affine(x, g, b)
+    assert y.dtype == HF and rel_l2(y, S.layer_norm_affine(f(x), f(g), f(b))) < TOL
+    a, c = rnd(2, 5, 5, 320, seed=4), rnd(2, 5, 5, 640, seed=5)
+    assert torch.equal(ops.concat_channels(a, c).cpu(), torch.cat([a, c], -1).cpu())
+    z = rnd(2, 5, 5, 4, seed=6)
+    pz = ops.concat_channels(z, None, pad_to=64).cpu()
+    assert pz.dtype == HF and torch.equal(pz[..., :4], z.cpu()) and torch.count_nonzero(pz[..., 4:]) == 0
+    t = torch.tensor([999.0, 500.0, 333.25, 0.0])
+    got = ops.sincos_embed(t.to(dev), sinusoidal_sigmas(320).to(dev), HF)
+    assert got.dtype == HF and (f(got) - S.sinusoidal_encoding(t, 320)).abs().max() < 1e-3
+    v = rnd(5, 1280, seed=7, scale=2.0)
+    assert rel_l2(ops.silu(v), O.silu(f(v))) < TOL
+    w, bb = rnd(640, 1280, seed=8, scale=0.03), rnd(640, seed=9)
+    assert rel_l2(ops.small_linear(v, w, bb), O.linear(f(v), f(w), f(bb))) < TOL
+    assert rel_l2(ops.small_linear(v, w, bb, silu_in=True), O.linear(O.silu(f(v)).to(HF).float(), f(w), f(bb))) < TOL
+    out = ops.small_linear(v, w, bb)
+    ops.small_linear(v, w, None, out=out, accum=True)
+    assert rel_l2(out, O.linear(f(v), f(w), f(bb)) + O.linear(f(v), f(w), None)) < 1e-3
+    xx, yy, zz = rnd(3, 1000, seed=10), rnd(3, 1000, seed=11), rnd(3, 1000, seed=12)
+    assert rel_l2(ops.axpbypcz(xx, yy, zz, 1.5, -0.25, 0.75), 1.5 * f(xx) - 0.25 * f(yy) + 0.75 * f(zz)) < TOL
+    coef = torch.tensor([7.72, -7.6, 0.84], dtype=torch.float32, device=dev)
+    assert rel_l2(ops.axpbypcz_dev(xx, yy, zz, coef), 7.72 * f(xx) - 7.6 * f(yy) + 0.84 * f(zz)) < TOL
+    idx = torch.tensor([[3, 1, 7, 7], [0, 2, 9, 5]], dtype=torch.int32, device=dev)
+    table, pos = rnd(10, 64, seed=13), rnd(4, 64, seed=14)
+    e = ops.embedding(idx, table, pos)
+    assert e.dtype == HF and rel_l2(e, f(table)[idx.cpu().long()] + f(pos)[None]) < TOL
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk", [(2, 5, 256, 256), (1, 10, 1024, 1024), (2, 3, 200, 77), (1, 2, 64, 13)])
+def test_attention_d64_f16(dev, B, H, Tq, Tk):
+    from flux_generator_amd import ops
+    C = H * 64
+    q, k, v = rnd(B, Tq, C, seed=1), rnd(B, Tk, C, seed=2), rnd(B, Tk, C, seed=3)
+    Tkpad = (Tk + 63) // 64 * 64
+    vt = torch.zeros(B, C, Tkpad, dtype=HF, device=dev)
+    vt[..., :Tk] = v.transpose(1, 2)
+    o = torch.empty(B, Tq, C, dtype=HF, device=dev)
+    ops.attention_strided(q, k, vt, o, B, H, 64, Tq, Tk, Tkpad, (Tq * C, 64, C), (Tk * C, 64, C), C, 64 ** -0.5)
+    sp = lambda t, T: f(t).view(B, T, H, 64).transpose(1, 2)   # noqa: E731
+    ref = O.sdpa(sp(q, Tq), sp(k, Tk), sp(v, Tk), 64 ** -0.5).transpose(1, 2).reshape(B, Tq, C)
+    assert rel_l2(o, ref) < 1e-3
+    # causal (CLIP towers)
+    if Tq == Tk:
+        o2 = torch.empty_like(o)
+        ops.attention_masked(q, k, vt, o2, B, H, Tq, Tk, Tkpad, (Tq * C, 64, C), (Tk * C, 64, C), C, 64 ** -0.5, causal=True)
+        s = torch.matmul(sp(q, Tq), sp(k, Tk).transpose(-1, -2)) * 64 ** -0.5
+        s = s.masked_fill(torch.triu(torch.ones(Tq, Tk, dtype=torch.bool), 1), float("-inf"))
+        refc = torch.matmul(torch.softmax(s, -1), sp(v, Tk)).transpose(1, 2).reshape(B, Tq, C)
+        assert rel_l2(o2, refc) < 1e-3
+
+
+def test_pixel_linear_x3_f16_input(dev):
+    """The fp32-faithful VAE's first op on float16 latents: z / scaling_factor is rounded to float16 (the reference divides a
+    float16 array), then the float32 post_quant_proj."""
+    from flux_generator_amd import ops
+    z = rnd(2, 8, 8, 4, seed=1, scale=3.0)
+    w, b = torch.randn(4, 4).to(dev), torch.randn(4).to(dev)
+    got = ops.join_f32(ops.pixel_linear_x3(z, w, b, 64, 0.13025))
+    zs = (z.cpu() / 0.13025).float()             # float16 division, then promoted
+    ref = torch.nn.functional.linear(zs, w.cpu(), b.cpu())
+    assert rel_l2(got[..., :4], ref) < 1e-5 and torch.count_nonzero(got[..., 4:]) == 0
+
+
+# ------------------------------------------------------------------------------------------------ models
+def tiny_unet_cfg(xl=True):
+    kw = dict(block_out_channels=(64, 128), layers_per_block=(1, 1), transformer_layers_per_block=(1, 2),
+              num_attention_heads=(1, 2), cross_attention_dim=(128, 128), down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"),
+              up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"))
+    if xl:
+        kw.update(addition_embed_type="text_time", addition_time_embed_dim=32, projection_class_embeddings_input_dim=48 + 6 * 32)
+    return kw
+
+
+def build_unet(dev, xl=True, seed=0):
+    from flux_generator_amd.stable_diffusion.config import UNetConfig
+    from flux_generator_amd.stable_diffusion.unet import UNetModel
+    kw = tiny_unet_cfg(xl)
+    ocfg = S.UNetConfig(**kw)
+    W = {k: v.to(HF).float() for k, v in O.init_weights(S.unet_weight_shapes(ocfg), seed=seed, norm_jitter=0.2).items()}
+    model = UNetModel(UNetConfig(**kw), device=dev, dtype=HF).load_weights(W)
+    assert all(t.dtype == HF for t in model.parameters().values())
+    return ocfg, W, model
+
+
+@pytest.mark.parametrize("xl,B", [(True, 2), (False, 2), (True, 6)])
+def test_unet_forward_tiny_f16(dev, xl, B):
+    """Tiny UNet in float16 against the oracle in float32 AND in float16 (= the reference's arithmetic: every op output
+    rounded to float16).  B = 6 takes the batched time-projection route (silu once + MFMA GEMM)."""
+    ocfg, W, model = build_unet(dev, xl)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 16, 16, 4, generator=g).to(HF)
+    enc = torch.randn(B, 7, 128, generator=g).to(HF)
+    t = torch.full((B,), 999.0)
+    tt = None
+    if xl:
+        tt = (torch.randn(B, 48, generator=g).to(HF), torch.tensor([[512, 512, 0, 0, 512, 512.0]] * B))
+    ref32 = S.unet_forward(ocfg, W, x.float(), t, enc.float(), None if tt is None else (tt[0].float(), tt[1]))
+    W16 = {k: v.to(HF) for k, v in W.items()}
+    ref16 = S.unet_forward(ocfg, W16, x, t, enc, tt)
+    got = model(x.to(dev), t.to(dev), enc.to(dev), text_time=None if tt is None else (tt[0].to(dev), tt[1].to(dev)))
+    e32, e16, eo = rel_l2(got, ref32), rel_l2(got, ref16), rel_l2(ref16, ref32)
+    print(f"unet tiny float16: HIP vs float32 oracle {e32:.2e}, HIP vs float16 oracle {e16:.2e}, float16 oracle vs float32 {eo:.2e}")
+    assert got.dtype == HF and got.shape == ref32.shape
+    assert e32 < 3e-3 and e16 < 3e-3
+    # bfloat16 storage on the same weights (the float16=False route): stated 1.5e-2, i.e. several times further away
+    from flux_generator_amd.stable_diffusion.config import UNetConfig
+    from flux_generator_amd.stable_diffusion.unet import UNetModel
+    mb = UNetModel(UNetConfig(**tiny_unet_cfg(xl)), device=dev, dtype=BF).load_weights(W)
+    gb = mb(x.to(dev).to(BF), t.to(dev), enc.to(dev).to(BF),
+            text_time=None if tt is None else (tt[0].to(dev).to(BF), tt[1].to(dev)))
+    assert rel_l2(gb, ref32) > 2 * e32
+
+
+def test_sd_step_and_samplers_f16(dev):
+    """One float16 denoising step (CFG batch doubling + Euler; ancestral with given noise) against the oracle run in float16:
+    sigma / sigma_prev cast to float16 first and the coefficients derived in it (sampler.py:77-78,90-96)."""
+    from flux_generator_amd.stable_diffusion.config import DiffusionConfig
+    from flux_generator_amd.stable_diffusion.sampler import SimpleEulerAncestralSampler, SimpleEulerSampler
+    dc = DiffusionConfig(beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012, num_train_steps=1000)
+    odc = S.DiffusionConfig()
+    g = torch.Generator().manual_seed(1)
+    x, eps, noise = (torch.randn(2, 8, 8, 4, generator=g).to(HF) for _ in range(3))
+    for cls, ocls in ((SimpleEulerSampler, S.EulerSampler), (SimpleEulerAncestralSampler, S.EulerAncestralSampler)):
+        smp, osmp = cls(dc), ocls(odc)
+        smp.coef_dtype = HF
+        steps = smp.timesteps(3, dtype=HF)
+        assert steps == [(1000.0, 666.5), (666.5, 333.25), (333.25, 0.0)]     # the float16-rounded schedule of the reference
+        for t, tp in steps:
+            got = smp.step(eps.to(dev), x.to(dev), t, tp, noise.to(dev)) if smp.needs_noise else smp.step(eps.to(dev), x.to(dev), t, tp)
+            ref16 = osmp.step(eps, x, t, tp, noise) if smp.needs_noise else osmp.step(eps, x, t, tp)
+            ref32 = osmp.step(eps.float(), x.float(), t, tp, noise.float()) if smp.needs_noise else osmp.step(eps.float(), x.float(), t, tp)
+            assert got.dtype == HF and rel_l2(got, ref16) < 2e-3 and rel_l2(got, ref32) < 2e-3
+
+
+def test_clip_tower_f16(dev):
+    """The CLIP text transformer (quick_gelu and exact-gelu towers) in float16 against the float32 text oracle."""
+    from flux_generator_amd.flux.clip import CLIPTextModel, CLIPTextModelConfig
+    for act, proj in (("quick_gelu", None), ("gelu", 96)):
+        cfg = CLIPTextModelConfig(num_layers=3, model_dims=128, num_heads=2, max_length=77, vocab_size=1000, hidden_act=act,
+                                  projection_dim=proj)
+        m = CLIPTextModel(cfg, device=dev, dtype=HF).init_random(4)
+        W = {k: f(v) for k, v in m.parameters().items()}
+        tok = torch.tensor([[1, 5, 9, 999, 0, 0, 0, 0], [2, 7, 999, 0, 0, 0, 0, 0]], dtype=torch.int32)
+        out = m(tok)
+        ocfg = TO.CLIPTextModelConfig(num_layers=3, model_dims=128, num_heads=2, max_length=77, vocab_size=1000, hidden_act=act,
+                                      projection_dim=proj)
+        ref = TO.clip_text_model(ocfg, W, tok)
+        assert out.last_hidden_state.dtype == HF
+        assert rel_l2(out.last_hidden_state, ref.last_hidden_state) < 2e-3
+        assert rel_l2(out.pooled_output, ref.pooled_output) < 2e-3
+        assert rel_l2(out.hidden_states[-2], ref.hidden_states[-2]) < 2e-3
+
+
+def _tiny_sd_zoo(monkeypatch, xl):
+    """Small UNet / VAE patched into the model table; the REAL text towers' widths (2 layers each) as in tests/test_sd_gpu.py."""
+    from flux_generator_amd.stable_diffusion import model_io
+    from flux_generator_amd.stable_diffusion.config import AutoencoderConfig, UNetConfig
+    key = "stabilityai/sdxl-turbo" if xl else "stabilityai/stable-diffusion-2-1-base"
+    kw = tiny_unet_cfg(xl)
+    if xl:
+        kw.update(cross_attention_dim=(768 + 1280,) * 2, projection_class_embeddings_input_dim=1280 + 6 * 32)
+        vae = AutoencoderConfig(block_out_channels=(128, 128), layers_per_block=1)
+        towers = ("text_encoder", "text_encoder_2")
+    else:
+        kw.update(cross_attention_dim=(1024, 1024))
+        vae = AutoencoderConfig(block_out_channels=(128, 128), layers_per_block=1, scaling_factor=0.18215)
+        towers = ("text_encoder",)
+    monkeypatch.setitem(model_io._MODELS, key, {**model_io._MODELS[key], "unet_config": UNetConfig(**kw), "vae_config": vae})
+    for mk in towers:
+        monkeypatch.setitem(model_io._TEXT_CONFIGS, (key, mk), {**model_io._TEXT_CONFIGS[(key, mk)], "num_layers": 2})
+    monkeypatch.delenv("SD_WEIGHTS_DIR", raising=False)
+    return key
+
+
+@pytest.mark.parametrize("xl", [True, False])
+def test_pipeline_float16_is_float16_end_to_end(dev, monkeypatch, xl):
+    """StableDiffusion[XL](float16=True): UNet, text towers, latents and sampler all float16 (nothing silently bf16), graph ==
+    eager bit for bit, images finite; float16=False keeps bfloat16 storage."""
+    import warnings
+    from flux_generator_amd.stable_diffusion import StableDiffusion, StableDiffusionXL
+    key = _tiny_sd_zoo(monkeypatch, xl)
+    cls = StableDiffusionXL if xl else StableDiffusion
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sd = cls(key, float16=True)
+        sd_eager = cls(key, float16=True, use_graph=False)
+        sd_bf = cls(key, float16=False)
+    assert sd.dtype == HF and sd_bf.dtype == BF and sd.sampler.coef_dtype == HF and sd_bf.sampler.coef_dtype == torch.float32
+    assert all(t.dtype == HF for t in sd.unet.parameters().values())
+    assert all(t.dtype == BF for t in sd_bf.unet.parameters().values())
+    tower = sd.text_encoder_2 if xl else sd.text_encoder
+    assert all(t.dtype == HF for t in tower.parameters().values())
+    kw = dict(n_images=2, num_steps=2, cfg_weight=(0.0 if xl else 7.5), latent_size=(16, 16), seed=3)
+    lat = list(sd.generate_latents("a cat", **kw))
+    lat_e = list(sd_eager.generate_latents("a cat", **kw))
+    assert all(x.dtype == HF for x in lat) and len(lat) == 2
+    for a, b in zip(lat, lat_e):
+        assert torch.equal(a, b), "graph replay differs from the eager float16 path"
+    img = sd.decode(lat[-1])
+    assert img.dtype == torch.float32 and img.shape == (2, 32, 32, 3) and bool(torch.isfinite(img).all())
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
