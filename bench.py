@@ -238,6 +238,9 @@ def dry_run(args) -> None:
     os.environ.setdefault("WORLD_SIZE", "1")
     dist.init_process_group("gloo")
     dev = torch.device("cpu")
+    placement = parallel.bind_rank_to_cpus(int(os.environ.get("LOCAL_RANK", rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    placements = [None] * world
+    dist.all_gather_object(placements, placement)
     B, lat = args.batch, 8
     S = 512 if args.model == "flux-dev" else 256
     calls = []
@@ -262,7 +265,7 @@ def dry_run(args) -> None:
         assert [int(gathered[r * B, 0, 0, 0]) for r in range(world)] == list(range(1, world + 1))
         print(json.dumps({"metric": "dry run (no kernels)", "value": None, "unit": "images/sec", "n_gpus": world, "dry_run": True,
                           "steps": args.steps, "warmup": args.warmup, "scaling": "weak", "backend": "gloo",
-                          "ranks_joined": world, "conditioning_evaluated_on_ranks": [0],
+                          "ranks_joined": world, "conditioning_evaluated_on_ranks": [0], "placement": placements,
                           "per_rank_ms": [float(t.item()) * 1e3 for t in allel],
                           "config": {"workload": "launch / sharding / collective skeleton", "global_batch": B * world}}), flush=True)
     dist.barrier()
@@ -331,6 +334,11 @@ def main() -> None:
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    # N > 1: pin this rank's threads to its share of the CPUs of its GPU's NUMA node (8 ranks x graph launches + OpenMP pools)
+    from flux_generator_amd import parallel as _par
+    placement = _par.bind_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), dev.index) if world > 1 else None
+    if placement and placement.get("cpus") and "OMP_NUM_THREADS" in os.environ:
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), int(placement["cpus"].split("(")[1].rstrip(")")))))
 
     from flux_generator_amd.flux.flux import FluxPipeline
     import warnings
@@ -380,11 +388,20 @@ def main() -> None:
         return
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    host_us = None
+    ev_start, ev_first = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_start.record()
+    for i in range(args.steps):
+        h0 = time.perf_counter()
         img = one_pass()
+        if i == 0:
+            host_us = (time.perf_counter() - h0) * 1e6     # host time to ENQUEUE one step (graph launches + glue); no sync here
+            ev_first.record()                              # GPU-side end of this rank's first step after the common barrier
     sync_all()
     elapsed = time.perf_counter() - t0
     per_rank_ms = [elapsed / args.steps * 1e3]
+    rank_diag = [{"rank": rank, "first_step_ms": ev_start.elapsed_time(ev_first), "enqueue_host_us_per_step": host_us,
+                  "placement": placement}]
     if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], device="cpu" if share_gpu else dev, dtype=torch.float64)
@@ -393,6 +410,9 @@ def main() -> None:
         per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        gathered_diag = [None] * world
+        dist.all_gather_object(gathered_diag, rank_diag[0])
+        rank_diag = gathered_diag
     assert img.shape == (B, args.image_size, args.image_size, 3) and bool(torch.isfinite(img).all())
     # after the timed region: uint8 images of every rank gathered on rank 0 (RCCL), as the CLI does before saving
     gathered = pipe.gather_images(img, B * world)
@@ -473,6 +493,8 @@ def main() -> None:
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms), "ranks": per_rank_ms},
+            "first_step_skew_ms": max(d["first_step_ms"] for d in rank_diag) - min(d["first_step_ms"] for d in rank_diag),
+            "per_rank": rank_diag,
             "collectives": (("gloo; ALL RANKS SHARE ONE GPU (BENCH_SHARE_GPU diagnostic): not a scaling measurement" if share_gpu else
                              f"RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())} (torch.distributed nccl backend)") if use_dist else None),
             "dtype": "fp8 e4m3 (block Linears: weights per-channel, activations per-token; residual stream / attention / VAE as in bf16 mode)" if args.fp8 else "bf16",

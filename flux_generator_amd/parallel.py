@@ -224,3 +224,64 @@ def broadcast_from(make, device, src: int = 0):
 def to_uint8(images: torch.Tensor) -> torch.Tensor:
     """(x*255).astype(uint8): float->uint8 TRUNCATION like the reference (txt2image.py:133,144)."""
     return (images * 255).to(torch.uint8)
+
+
+# ---------------------------------------------------------------------------------------------- host-side placement
+def partition_cpus(cpus, local_rank: int, local_world: int):
+    """Contiguous, balanced slice of a sorted CPU list for one of `local_world` ranks sharing it (every rank gets at
+    least one CPU; the first len % world ranks take one extra)."""
+    cpus = sorted(cpus)
+    if local_world <= 1 or len(cpus) < local_world:
+        return cpus
+    lo, hi = shard_range(len(cpus), local_rank, local_world)
+    return cpus[lo:hi]
+
+
+def _parse_cpulist(text: str):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_node(index: int) -> int:
+    """NUMA node of GPU `index` (its PCI function's sysfs `numa_node`), or -1 when the platform does not say."""
+    try:
+        bus = torch.cuda.get_device_properties(index).pci_bus_id if hasattr(torch.cuda.get_device_properties(index), "pci_bus_id") else None
+        if bus is None:
+            p = torch.cuda.get_device_properties(index)
+            bus = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{str(bus).lower()}/numa_node") as f:
+            return int(f.read().strip())
+    except Exception:
+        return -1
+
+
+def bind_rank_to_cpus(local_rank: int, local_world: int, gpu_index: Optional[int] = None) -> dict:
+    """One process per GPU also means one launch thread per GPU: eight ranks whose threads wander over all sockets pay
+    cross-socket latency on every graph launch and fight each other's OpenMP pools.  Pin this rank to its share of the
+    CPUs of ITS GPU's NUMA node (sysfs; all allowed CPUs when the node is unknown), split evenly among the ranks on that
+    node.  Best effort, never fatal; returns what was done for the bench record."""
+    import os
+    info = {"numa_node": -1, "cpus": None, "bound": False}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        node = gpu_numa_node(gpu_index if gpu_index is not None else local_rank) if torch.cuda.is_available() else -1
+        pool, peers, me = allowed, local_world, local_rank
+        if node >= 0:
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                node_cpus = [c for c in _parse_cpulist(f.read()) if c in set(allowed)]
+            same = [r for r in range(local_world) if gpu_numa_node(r) == node] if torch.cuda.device_count() >= local_world else []
+            if node_cpus and local_rank in same:
+                pool, peers, me = node_cpus, len(same), same.index(local_rank)
+        mine = partition_cpus(pool, me, peers)
+        if mine and len(mine) < len(allowed):
+            os.sched_setaffinity(0, mine)
+            info["bound"] = True
+        info.update(numa_node=node, cpus=f"{mine[0]}-{mine[-1]} ({len(mine)})" if mine else None)
+    except Exception as e:      # containers without sysfs, restricted cpusets, ...
+        info["error"] = f"{type(e).__name__}: {e}"
+    return info

@@ -137,6 +137,30 @@ def test_bench_gpus2_launches_two_ranks():
     assert out["config"]["global_batch"] == 2 and out["scaling"] == "weak"
 
 
+def test_bench_gpus8_dry_run_and_cpu_placement():
+    """The launch an 8-GPU node gets, on CPU: `python bench.py --gpus 8 --dry-run` starts 8 ranks (gloo), every rank joins the
+    broadcast / barrier / max-reduce / gather skeleton, and every rank pins itself to its own share of the CPUs
+    (parallel.bind_rank_to_cpus: disjoint slices when there are at least 8 CPUs)."""
+    r, out = _run_bench("--gpus", "8", "--dry-run", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out is not None and out["n_gpus"] == 8 and out["ranks_joined"] == 8 and len(out["per_rank_ms"]) == 8
+    assert out["conditioning_evaluated_on_ranks"] == [0] and out["config"]["global_batch"] == 8
+    pl = out["placement"]
+    assert len(pl) == 8 and all(p is not None and "error" not in p for p in pl)
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert all(p["bound"] for p in pl) and len({p["cpus"] for p in pl}) == 8
+
+
+def test_partition_cpus():
+    from flux_generator_amd.parallel import _parse_cpulist, partition_cpus
+    cpus = _parse_cpulist("0-5,8,10-12")
+    assert cpus == [0, 1, 2, 3, 4, 5, 8, 10, 11, 12]
+    parts = [partition_cpus(cpus, r, 4) for r in range(4)]
+    assert sum(parts, []) == cpus and [len(p) for p in parts] == [3, 3, 2, 2]
+    assert partition_cpus([3, 1], 0, 4) == [1, 3]          # fewer CPUs than ranks: everybody keeps them all
+    assert partition_cpus(cpus, 0, 1) == cpus
+
+
 def test_bench_refuses_world_size_mismatch():
     """--gpus must agree with the launcher's WORLD_SIZE: a mismatch is an error, not a silent 1-rank run."""
     r, out = _run_bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0"})

@@ -124,3 +124,50 @@ def test_gelu_erf_epilogue(dev):
     n, w, b = rnd(40, 128, seed=5), rnd(256, 128, seed=6, scale=0.1), rnd(256, seed=7)
     ref = torch.nn.functional.gelu(O.linear(n.float().cpu(), w.float().cpu(), b.float().cpu()))
     assert rel_l2(ops.linear(n, w, b, epi=ops.EPI_GELU_ERF), ref) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------ real widths
+def test_t5_xxl_width_two_layers(dev):
+    """T5-XXL's real shapes (flux/t5.py:119-189,227-244; google/t5-v1_1-xxl encoder): d_model 4096, 64 heads x 64,
+    d_ff 10240 gated-gelu, 32 relative-position buckets, S = 512 (the dev pipeline's padded length) — a 2-layer slice of
+    the 24-layer stack against the text oracle.  One layer at this width is 0.9 TFLOP on the host: 2 layers keep the oracle
+    at seconds.  Bound: the tiny models' 1.5e-2 (bf16 storage, fp32 accumulate)."""
+    from flux_generator_amd.flux.t5 import T5Config, T5Encoder
+    kw = dict(vocab_size=32128, num_layers=2, num_heads=64, relative_attention_num_buckets=32, d_kv=64, d_model=4096,
+              feed_forward_proj="gated-gelu", tie_word_embeddings=False, d_ff=10240)
+    ocfg = T.T5Config(**{k: v for k, v in kw.items() if k in T.T5Config.__dataclass_fields__})
+    shapes = T.t5_weight_shapes(ocfg)
+    W = {k: v.to(BF).float() for k, v in O.init_weights(shapes, seed=0, norm_jitter=0.2).items()}
+    g = torch.Generator().manual_seed(1)
+    W["wte.weight"] = torch.randn(32128, 4096, generator=g).to(BF).float()
+    W["encoder.relative_attention_bias.embeddings.weight"] = torch.randn(32, 64, generator=g).to(BF).float()
+    model = T5Encoder(T5Config(**kw), device=dev).load_weights(W)
+    tokens = torch.randint(2, 32000, (1, 512), generator=torch.Generator().manual_seed(3))
+    tokens[0, 40] = 1                                             # EOS, then pads: attended like every other token
+    tokens[0, 41:] = 0
+    got = model(tokens)
+    with torch.no_grad():
+        ref = T.t5_encoder(ocfg, W, tokens)
+    e = rel_l2(got, ref)
+    print(f"T5-XXL width, 2 layers, S = 512: rel-L2 {e:.2e}")
+    assert got.shape == (1, 512, 4096) and e < 1.5e-2
+
+
+def test_clip_l_real_width_full_depth(dev):
+    """CLIP-L text tower as shipped with FLUX.1 (flux/clip.py:96-150; openai/clip-vit-large-patch14): 12 layers, 768 wide,
+    12 heads x 64, 77 positions, vocabulary 49408 — the whole tower against the text oracle."""
+    from flux_generator_amd.flux.clip import CLIP_L, CLIPTextModel, CLIPTextModelConfig
+    ocfg = T.CLIPTextModelConfig(**CLIP_L)
+    W = {k: v.to(BF).float() for k, v in O.init_weights(T.clip_weight_shapes(ocfg), seed=4, norm_jitter=0.2).items()}
+    for k in ("token_embedding.weight", "position_embedding.weight"):
+        W[k] = (torch.randn(W[k].shape, generator=torch.Generator().manual_seed(5)) * 0.5).to(BF).float()
+    model = CLIPTextModel(CLIPTextModelConfig(**CLIP_L), device=dev).load_weights(W)
+    tokens = torch.randint(1, 49000, (2, 77), generator=torch.Generator().manual_seed(6))
+    tokens[:, 0] = 49406
+    tokens[0, 9:] = 49407
+    tokens[1, 30:] = 49407
+    got = model(tokens)
+    ref = T.clip_text_model(ocfg, W, tokens)
+    e, ep = rel_l2(got.last_hidden_state, ref.last_hidden_state), rel_l2(got.pooled_output, ref.pooled_output)
+    print(f"CLIP-L full tower: last_hidden_state rel-L2 {e:.2e}, pooled {ep:.2e}")
+    assert got.pooled_output.shape == (2, 768) and e < 1.5e-2 and ep < 1.5e-2

@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 pipe = StableDiffusion("stabilityai/stable-diffusion-2-1-base", float16=True)
 g = torch.Generator(device=dev).manual_seed(0)
 x_T = pipe.sampler.sample_prior((B, 64, 64, 4), key=g, device=dev)
-cond = torch.randn(2 * B, 77, 1024, generator=g, device=dev).to(torch.bfloat16)      # [text, negative]
+cond = torch.randn(2 * B, 77, 1024, generator=g, device=dev).to(pipe.dtype)      # [text, negative]
 def run():
     x = x_T
     for x in pipe._denoising_loop(x_T, pipe.sampler.max_time, cond, NSTEP, 7.5):

@@ -89,14 +89,14 @@ dev = torch.device("cuda:0")
 pipe = StableDiffusionXL("stabilityai/sdxl-turbo", float16=True)
 g = torch.Generator(device=dev).manual_seed(0)
 x_T = pipe.sampler.sample_prior((B, 64, 64, 4), key=g, device=dev)
-cond = torch.randn(B, 77, 2048, generator=g, device=dev).to(torch.bfloat16)
-pooled = torch.randn(B, 1280, generator=g, device=dev).to(torch.bfloat16)
+cond = torch.randn(B, 77, 2048, generator=g, device=dev).to(pipe.dtype)
+pooled = torch.randn(B, 1280, generator=g, device=dev).to(pipe.dtype)
 tt = (pooled, torch.tensor([[512, 512, 0, 0, 512, 512.0]] * B, device=dev))
 ts = torch.full((B,), 999.0, device=dev)
 for it in range(3):
     log.clear()
     e0, e1 = ev(), ev()
-    e0.record(); pipe.unet(x_T.to(torch.bfloat16), ts, cond, text_time=tt); e1.record()
+    e0.record(); pipe.unet(x_T.to(pipe.dtype), ts, cond, text_time=tt); e1.record()
     torch.cuda.synchronize()
 tot = 0.0
 agg = collections.OrderedDict()
