@@ -212,7 +212,18 @@ __global__ __launch_bounds__(256) void qk_norm_rope_vt_kernel(
       float x0 = rbf(v[2 * e] * rstd * bf_lo(ww[e]));      // RMSNorm output is a bf16 tensor
       float x1 = rbf(v[2 * e + 1] * rstd * bf_hi(ww[e]));
       float c = bf_lo(cs[e]), s = bf_hi(cs[e]);
-      o[e] = pack_bf16x2(x0 * c - x1 * s, x0 * s + x1 * c);
+      // Plain (unpacked) VALU ops, opaque to the compiler's packed-FP32 formation.  Written as C, hipcc turned this rotation
+      // into v_pk_mul_f32 / v_pk_fma_f32 sequences whose LOW results came out wrong in lanes 48-63 (the K rows of the odd heads)
+      // whenever another process shared the GPU - bit-stable alone, different on every run next to a co-tenant
+      // (tools/flux_contention_bisect.py located it: this launch, this statement; tools/contention_platform_probe.py shows
+      // the co-tenant need not be this library).  Two rewrites that stayed packed failed the same way; these four
+      // instructions per pair do not.  The library is also built with packed FP32 formation off (build.sh).
+      float t0, t1, r0, r1;
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(s), "v"(x1));
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(s), "v"(x0));
+      asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(r0) : "v"(c), "v"(x0), "v"(t0));
+      asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(c), "v"(x1), "v"(t1));
+      o[e] = pack_bf16x2(r0, r1);
     }
     if (live) {
       bf16_t* dst = (which ? Kout : Q) + (((long long)b * H + h) * T + t) * 128 + sub * 8;

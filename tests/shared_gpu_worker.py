@@ -4,6 +4,8 @@ same GPU at the same time, with the library's DEFAULT split-K hand-off (reduce-s
 the 240-block split-K grids of the two are not resident as a whole: the hand-off's bounded poll + orphan completion has to
 carry them (include/fluxhip.h, fluxhip_gemm_set_splitk_mode).
 
+`matmul` as the tag starts a co-tenant of plain torch.matmul kernels instead (it runs until <sync_dir>/done exists).
+
 usage: python tests/shared_gpu_worker.py <tag> <n_forwards> <sync_dir> <n_procs> <result.pt>"""
 import os
 import sys
@@ -14,7 +16,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def matmul_cotenant(sync_dir, n_procs):
+    """A co-tenant that is NOT this library: dependent torch.matmul / gelu kernels (hipBLASLt) until the workers are done."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    Ws = [(torch.randn(4096, 4096, generator=g) / 64).to(torch.bfloat16).to(dev) for _ in range(8)]
+    x0 = torch.randn(2048, 4096, generator=g).to(torch.bfloat16).to(dev)
+    open(os.path.join(sync_dir, "ready_matmul"), "w").close()
+    t0 = time.time()
+    while not os.path.exists(os.path.join(sync_dir, "done")) and time.time() - t0 < 600:
+        x = x0
+        for W in Ws * 6:
+            x = torch.nn.functional.gelu(x @ W) + 0.5
+        torch.cuda.synchronize()
+
+
 def main():
+    if sys.argv[1] == "matmul":
+        return matmul_cotenant(sys.argv[3], int(sys.argv[4]))
     tag, n_fwd, sync_dir, n_procs, out = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
     import torch
     warnings.simplefilter("ignore")

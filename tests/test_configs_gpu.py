@@ -591,11 +591,14 @@ def test_two_ranks_share_one_gpu_end_to_end(dev, tmp_path):
 
 
 def test_two_default_mode_processes_share_one_gpu(dev, tmp_path):
-    """Two independent processes run 20 full-size Flux-schnell forwards each (C2 shape) on this GPU AT THE SAME TIME with the
-    library's default split-K hand-off (reduce-scatter: 57 launches per forward whose S blocks per tile wait for each
-    other).  Neither process owns the GPU, so neither grid is resident as a whole — what used to deadlock and trap.  Both
-    must finish without a fault and produce the bits of a process that had the GPU to itself (the orphan completion of the
-    hand-off is bit-identical to its fast path).  tests/shared_gpu_worker.py."""
+    """Processes that do NOT own the GPU.  (1) Two independent processes run 20 dependent full-size Flux-schnell forwards each
+    (C2 shape) on this GPU AT THE SAME TIME with the library's default split-K hand-off (reduce-scatter: 57 launches per forward
+    whose S blocks per tile wait for each other) - neither grid is resident as a whole, which used to deadlock and trap.
+    (2) One such process next to a co-tenant that is not this library at all (a torch.matmul loop).  Every run must finish
+    without a fault and produce THE BITS of a process that had the GPU to itself: the orphan completion of the hand-off is
+    bit-identical to its fast path, and no kernel may depend on what a co-tenant leaves in the register file (round 4: one
+    compiler-formed packed-FP32 sequence in the q/k norm + RoPE kernel did; see csrc/norm.hip and csrc/build.sh).
+    tests/shared_gpu_worker.py."""
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shared_gpu_worker.py")
@@ -610,12 +613,20 @@ def test_two_default_mode_processes_share_one_gpu(dev, tmp_path):
     solo = launch("solo", tmp_path / "s1", 1)
     out = solo.communicate(timeout=900)[0]
     assert solo.returncode == 0, out[-2000:]
+    ref = torch.load(tmp_path / "solo.pt")
+    assert ref["finite"] and ref["rs_launches"] == 20 * 57
+    # (1) two workers
     procs = [launch(f"p{i}", tmp_path / "s2", 2) for i in range(2)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
-    ref = torch.load(tmp_path / "solo.pt")
-    assert ref["finite"] and ref["rs_launches"] == 20 * 57
-    for i in range(2):
+    # (2) a worker next to a torch.matmul co-tenant
+    co = launch("matmul", tmp_path / "s3", 2)
+    w3 = launch("p2", tmp_path / "s3", 2)
+    out3 = w3.communicate(timeout=900)[0]
+    open(tmp_path / "s3" / "done", "w").close()
+    co.communicate(timeout=120)
+    assert w3.returncode == 0 and co.returncode == 0, out3[-2000:]
+    for i in range(3):
         r = torch.load(tmp_path / f"p{i}.pt")
         assert r["rs_launches"] == 20 * 57, "the shared processes did not run the reduce-scatter hand-off"
         assert torch.equal(r["first"], ref["first"]) and torch.equal(r["last"], ref["last"]), f"process {i}"
