@@ -31,6 +31,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+os.environ.setdefault("FLUX_ALLOW_RANDOM_INIT", "1")   # random-init weights of the named architecture (no checkpoints here): stated in `data`
+
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_FP8_PEAK_TFLOPS = 5000.0    # dense, block-scaled K=128 fp8 MFMA (same guide)
 

@@ -78,6 +78,17 @@ def _hub_file(repo_id: Optional[str], filename: Optional[str], hf_download: bool
     return None
 
 
+def random_init_or_raise(what: str, how: str) -> None:
+    """No checkpoint for `what`.  The reference would call hf_hub_download here and fail without network
+    (flux/utils.py:102-110); a server that silently answers with noise images from random weights is worse than an error, so
+    random initialisation needs an explicit FLUX_ALLOW_RANDOM_INIT=1 (tests, bench.py and the tools set it: this build's
+    environments have no checkpoints).  `how` names the configuration that would supply real weights."""
+    if os.environ.get("FLUX_ALLOW_RANDOM_INIT") != "1":
+        raise FileNotFoundError(f"{what}: no weights found ({how}). Set FLUX_ALLOW_RANDOM_INIT=1 to run on random-initialised "
+                                "weights (benchmarks / tests only: the images are noise).")
+    warnings.warn(f"{what}: no weights found ({how}); FLUX_ALLOW_RANDOM_INIT=1 -> random-init weights")
+
+
 def _receives_weights(from_rank0: bool) -> bool:
     """True on the ranks that skip the disk read and take the weights from rank 0 over RCCL."""
     from .. import parallel
@@ -103,8 +114,8 @@ def _load_flow_local(model: Flux, name: str, spec: ModelSpec, seed: int, hf_down
     if path is not None:
         model.load_weights(model.sanitize(_load_safetensors(path)))
     else:
-        warnings.warn(f"{name}: no checkpoint configured (set FLUX_SCHNELL / FLUX_DEV, or FLUX_HUB_DOWNLOAD=1 with network "
-                      "access, or pre-populate the Hugging Face cache); using random-init weights")
+        random_init_or_raise(f"{name} flow model", "set FLUX_SCHNELL / FLUX_DEV, or FLUX_HUB_DOWNLOAD=1 with network access, or "
+                             "pre-populate the Hugging Face cache")
         model.init_random(seed)
     return model
 
@@ -127,8 +138,8 @@ def _load_ae_local(ae: AutoEncoder, name: str, spec: ModelSpec, seed: int, hf_do
     if path is not None:
         ae.load_weights(ae.sanitize(_load_safetensors(path)))   # strict: encoder.* keys are skipped explicitly
     else:
-        warnings.warn(f"{name}: no AE checkpoint configured (set AE, or FLUX_HUB_DOWNLOAD=1 with network access, or "
-                      "pre-populate the Hugging Face cache); using random-init weights")
+        random_init_or_raise(f"{name} autoencoder", "set AE, or FLUX_HUB_DOWNLOAD=1 with network access, or pre-populate the "
+                             "Hugging Face cache")
         ae.init_random(seed)
     return ae
 
@@ -150,7 +161,7 @@ def load_clip(name: str, device="cuda", seed: int = 2) -> CLIPTextModel:
         with open(os.path.join(d, "text_encoder", "config.json")) as f:
             clip = CLIPTextModel(CLIPTextModelConfig.from_dict(json.load(f)), device=device)
         return clip.load_weights(clip.sanitize(_load_safetensors(os.path.join(d, "text_encoder", "model.safetensors"))))
-    warnings.warn("CLIP text encoder: FLUX_TEXT_DIR not set; random-init CLIP-L architecture")
+    random_init_or_raise("CLIP text encoder", "point FLUX_TEXT_DIR at a copy of the hub layout (text_encoder/)")
     return CLIPTextModel(CLIPTextModelConfig(**CLIP_L), device=device).init_random(seed)
 
 
@@ -168,7 +179,7 @@ def load_t5(name: str, device="cuda", seed: int = 3) -> T5Encoder:
         for w in files:
             weights.update(_load_safetensors(os.path.join(d, "text_encoder_2", w)))
         return t5.load_weights(t5.sanitize(weights))    # strict: decoder.* / lm_head.* keys are skipped explicitly
-    warnings.warn("T5 encoder: FLUX_TEXT_DIR not set; random-init T5-XXL encoder architecture")
+    random_init_or_raise("T5-XXL encoder", "point FLUX_TEXT_DIR at a copy of the hub layout (text_encoder_2/)")
     return T5Encoder(T5Config(**T5_XXL), device=device).init_random(seed)
 
 

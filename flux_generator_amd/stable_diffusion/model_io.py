@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 
 from ..flux.text import HashTokenizer
+from ..flux.utils import random_init_or_raise
 from ..flux.tokenizers import CLIPTokenizer
 from .clip import CLIPTextModel, CLIPTextModelConfig, map_clip_text_encoder_weights
 from .config import AutoencoderConfig, DiffusionConfig, UNetConfig
@@ -139,7 +140,7 @@ def load_unet(key: str = _DEFAULT_MODEL, float16: bool = False, device="cuda", s
     if path:
         model.load_weights(_load_mapped(map_unet_weights, path))
     else:
-        warnings.warn(f"{key}: no UNet weights under SD_WEIGHTS_DIR; using random-init weights")
+        random_init_or_raise(f"{key} UNet", "put the hub files under SD_WEIGHTS_DIR")
         model.init_random(seed)
     return model
 
@@ -151,7 +152,7 @@ def load_autoencoder(key: str = _DEFAULT_MODEL, float16: bool = False, device="c
     if path:
         model.load_weights(_load_mapped(map_vae_weights, path))   # strict: encoder.* / quant_proj keys are skipped explicitly
     else:
-        warnings.warn(f"{key}: no VAE weights under SD_WEIGHTS_DIR; using random-init weights")
+        random_init_or_raise(f"{key} VAE", "put the hub files under SD_WEIGHTS_DIR")
         model.init_random(seed)
     return model
 
@@ -192,8 +193,7 @@ def load_text_encoder(key: str = _DEFAULT_MODEL, float16: bool = False, model_ke
     if path:
         model.load_weights(_load_mapped(map_clip_text_encoder_weights, path))
     else:
-        warnings.warn(f"{key}: no {model_key} weights under SD_WEIGHTS_DIR; using a random-init CLIP text transformer "
-                      "(images will not follow the prompt)")
+        random_init_or_raise(f"{key} {model_key}", "put the hub files under SD_WEIGHTS_DIR")
         model.init_random(seed + (1 if model_key.endswith("_2") else 0))
     return model
 

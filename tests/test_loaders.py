@@ -221,3 +221,18 @@ def test_text_checkpoints_and_tokenizers_load_from_hub_layout(dev, tmp_path, mon
     ttok = utils.load_t5_tokenizer("flux-schnell")
     ids = ttok.tokenize("a photo of a cat")
     assert len(ids) == 256 and 1 in ids and ids[-1] == 0
+
+
+def test_random_init_is_an_explicit_opt_in(monkeypatch):
+    """A missing checkpoint raises (the reference's hf_hub_download would fail without network, flux/utils.py:102-110) unless
+    FLUX_ALLOW_RANDOM_INIT=1 asks for random weights (tests, bench.py): a mis-configured server must not answer with noise."""
+    import warnings
+    from flux_generator_amd.flux.utils import random_init_or_raise
+    monkeypatch.delenv("FLUX_ALLOW_RANDOM_INIT", raising=False)
+    with pytest.raises(FileNotFoundError, match="FLUX_ALLOW_RANDOM_INIT=1"):
+        random_init_or_raise("flux-schnell flow model", "set FLUX_SCHNELL")
+    monkeypatch.setenv("FLUX_ALLOW_RANDOM_INIT", "1")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        random_init_or_raise("flux-schnell flow model", "set FLUX_SCHNELL")
+    assert len(w) == 1 and "random-init" in str(w[0].message)

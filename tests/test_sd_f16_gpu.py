@@ -382,3 +382,27 @@ def test_pipeline_float16_is_float16_end_to_end(dev, monkeypatch, xl):
     img = sd.decode(lat[-1])
     assert img.dtype == torch.float32 and img.shape == (2, 32, 32, 3) and bool(torch.isfinite(img).all())
     assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+
+
+def test_interleaved_generators_keep_their_own_prompt(dev, monkeypatch):
+    """One captured UNet-step graph (keyed by shapes) serves every run of a pipeline; its static conditioning buffers follow the
+    caller's tensor (identity + version), so two generate_latents generators advanced alternately denoise with their OWN prompt:
+    each equals its uninterleaved run bit for bit."""
+    import warnings
+    from flux_generator_amd.stable_diffusion import StableDiffusion
+    key = _tiny_sd_zoo(monkeypatch, False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sd = StableDiffusion(key, float16=True)
+    kw = dict(n_images=1, num_steps=3, cfg_weight=7.5, latent_size=(16, 16))
+    a_alone = list(sd.generate_latents("a red cube", seed=1, **kw))
+    b_alone = list(sd.generate_latents("a photo of a dog on the moon", seed=2, **kw))
+    assert not torch.equal(a_alone[-1], b_alone[-1])
+    ga, gb = sd.generate_latents("a red cube", seed=1, **kw), sd.generate_latents("a photo of a dog on the moon", seed=2, **kw)
+    a_mix, b_mix = [], []
+    for _ in range(3):
+        a_mix.append(next(ga))
+        b_mix.append(next(gb))
+    assert all(torch.equal(x, y) for x, y in zip(a_mix, a_alone)), "generator A ran with generator B's prompt"
+    assert all(torch.equal(x, y) for x, y in zip(b_mix, b_alone)), "generator B ran with generator A's prompt"
+    assert len([k for k in sd._graphs if k[0] == "step"]) == 1
