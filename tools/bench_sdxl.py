@@ -14,7 +14,7 @@ steps = int(os.environ.get("SDXL_ITERS", "5"))
 dev = torch.device("cuda:0")
 pipe = StableDiffusionXL("stabilityai/sdxl-turbo", float16=True)
 g = torch.Generator(device=dev).manual_seed(0)
-x_T = pipe.sampler.sample_prior((B, 64, 64, 4), key=g, device=dev)
+x_T = pipe.sampler.sample_prior((B, 64, 64, 4), dtype=pipe.dtype, key=g, device=dev)
 cond = torch.randn(B, 77, 2048, generator=g, device=dev).to(pipe.dtype)
 pooled = torch.randn(B, 1280, generator=g, device=dev).to(pipe.dtype)
 tt = (pooled, torch.tensor([[512, 512, 0, 0, 512, 512.0]] * B, device=dev))

@@ -27,6 +27,7 @@ def load(path):
 F, W = load(fetch_csv), load(write_csv)
 with open(dst, "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --profile-only --no-graph\n")
+    f.write("# workload: " + (sys.argv[4] if len(sys.argv) > 4 else "flux-schnell B1 T1280") + "\n")
     f.write("# hbm_read_MB = FETCH_SIZE(KiB) * 2 * 1024 / 1e6 (gfx950 x2 correction); hbm_write_MB = WRITE_SIZE(KiB) * 1024 / 1e6\n")
     f.write("kernel,launches,avg_hbm_read_MB,avg_hbm_write_MB,avg_total_MB\n")
     for n in sorted(F, key=lambda k: -F[k][1]):
