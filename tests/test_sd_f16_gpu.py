@@ -395,10 +395,12 @@ def test_interleaved_generators_keep_their_own_prompt(dev, monkeypatch):
         warnings.simplefilter("ignore")
         sd = StableDiffusion(key, float16=True)
     kw = dict(n_images=1, num_steps=3, cfg_weight=7.5, latent_size=(16, 16))
-    a_alone = list(sd.generate_latents("a red cube", seed=1, **kw))
-    b_alone = list(sd.generate_latents("a photo of a dog on the moon", seed=2, **kw))
+    pa, pb = "a red cube", "one blue ball"                   # same token count: both runs share ONE step graph
+    a_alone = list(sd.generate_latents(pa, seed=1, **kw))
+    b_alone = list(sd.generate_latents(pb, seed=2, **kw))
     assert not torch.equal(a_alone[-1], b_alone[-1])
-    ga, gb = sd.generate_latents("a red cube", seed=1, **kw), sd.generate_latents("a photo of a dog on the moon", seed=2, **kw)
+    assert len([k for k in sd._graphs if k[0] == "step"]) == 1, "the two prompts did not share a step graph: pick equal token counts"
+    ga, gb = sd.generate_latents(pa, seed=1, **kw), sd.generate_latents(pb, seed=2, **kw)
     a_mix, b_mix = [], []
     for _ in range(3):
         a_mix.append(next(ga))

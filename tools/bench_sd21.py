@@ -1,11 +1,10 @@
-import os
 #!/usr/bin/env python3
 """SD 2.1-base 512x512 with classifier-free guidance (UNet batch 2 per image), 1 x MI355X, random-init weights, synthetic
 conditioning: UNet step ms (hipGraph replay), images/sec for a 50-step run incl. the float32-faithful decode."""
 import json, os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-os.environ.setdefault(\"FLUX_ALLOW_RANDOM_INIT\", \"1\")
+os.environ.setdefault("FLUX_ALLOW_RANDOM_INIT", "1")
 warnings.simplefilter("ignore")
 from flux_generator_amd.stable_diffusion import StableDiffusion
 

@@ -1,11 +1,10 @@
-import os
 #!/usr/bin/env python3
 """BASELINE.json config C4: stabilityai/sdxl-turbo 512x512 1-step, batch 16, 1 x MI355X (random-init weights,
 synthetic conditioning resident in HBM).  Prints one JSON line (images/sec, UNet step ms, decode ms)."""
 import json, os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-os.environ.setdefault(\"FLUX_ALLOW_RANDOM_INIT\", \"1\")
+os.environ.setdefault("FLUX_ALLOW_RANDOM_INIT", "1")
 warnings.simplefilter("ignore")
 from flux_generator_amd.stable_diffusion import StableDiffusionXL
 

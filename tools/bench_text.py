@@ -1,4 +1,3 @@
-import os
 #!/usr/bin/env python3
 """Text-encode step of the Flux pipelines (flux/flux.py:73-85; the tensors rank 0 broadcasts over RCCL): T5-XXL encoder
 (24 layers, d_model 4096, 64 x 64 heads, d_ff 10240) at S = 256 (schnell) / 512 (dev) and CLIP-L (12 layers, 768) at 77 tokens,
@@ -7,7 +6,7 @@ eager launches: the towers run once per job, there is no graph), algorithmic TFL
 import json, os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-os.environ.setdefault(\"FLUX_ALLOW_RANDOM_INIT\", \"1\")
+os.environ.setdefault("FLUX_ALLOW_RANDOM_INIT", "1")
 warnings.simplefilter("ignore")
 from flux_generator_amd.flux.utils import load_clip, load_t5
 

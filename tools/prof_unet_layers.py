@@ -5,7 +5,7 @@ import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import warnings; warnings.filterwarnings("ignore")
 import torch
-os.environ.setdefault(\"FLUX_ALLOW_RANDOM_INIT\", \"1\")
+os.environ.setdefault("FLUX_ALLOW_RANDOM_INIT", "1")
 from flux_generator_amd import ops, _lib
 from flux_generator_amd.stable_diffusion import StableDiffusionXL
 from flux_generator_amd.stable_diffusion import unet as unet_mod
