@@ -83,6 +83,20 @@ class CLIPTextModel:
             shp["text_projection.weight"] = (config.projection_dim, D)
         self._params = {k: torch.empty(*v, dtype=self.dtype, device=self.device) for k, v in shp.items()}
         self._qk: Dict[int, tuple] = {}
+        self.fp8 = False
+        self._w8: Dict[int, tuple] = {}
+
+    def enable_fp8(self, enabled: bool = True) -> "CLIPTextModel":
+        """`--quantize` on the CLIP tower (txt2image.py:79-82): the reference's predicate (in_dim % 512 == 0) selects the
+        layers' second MLP Linear only (in_dim = 4 x width; the width-768 / 1280 inputs of every other Linear do not pass it),
+        and so does this: e4m3 weights per output channel, per-token e4m3 inputs, fp8 MFMA (bf16 towers only)."""
+        if enabled and self.dtype != BF16:
+            raise ValueError("fp8 Linears are built for the bf16 towers")
+        if enabled and not self._w8 and (4 * self.config.model_dims) % 512 == 0:
+            for i in range(self.config.num_layers):
+                self._w8[i] = ops.quantize_rows_fp8(self._params[f"layers.{i}.linear2.weight"])
+        self.fp8 = bool(enabled)
+        return self
 
     def parameters(self):
         return self._params
@@ -133,10 +147,13 @@ class CLIPTextModel:
     def finalize(self) -> "CLIPTextModel":
         P = self._params
         self._qk = {}
+        was8, self._w8 = getattr(self, "fp8", False), {}
         for i in range(self.config.num_layers):
             a = f"layers.{i}.attention"
             self._qk[i] = (torch.cat([P[f"{a}.query_proj.weight"], P[f"{a}.key_proj.weight"]], 0).contiguous(),
                            torch.cat([P[f"{a}.query_proj.bias"], P[f"{a}.key_proj.bias"]], 0).contiguous())
+        if was8:
+            self.enable_fp8(True)
         return self
 
     def __call__(self, x: torch.Tensor) -> CLIPOutput:
@@ -169,7 +186,11 @@ class CLIPTextModel:
             h = ops.linear(o, P[f"{p}.attention.out_proj.weight"], P[f"{p}.attention.out_proj.bias"], epi=EPI_GATE_RES, res=h)
             y = ops.layernorm_affine(h, P[f"{p}.layer_norm2.weight"], P[f"{p}.layer_norm2.bias"])
             y = ops.linear(y, P[f"{p}.linear1.weight"], P[f"{p}.linear1.bias"], epi=_ACT_EPI[c.hidden_act])
-            h = ops.linear(y, P[f"{p}.linear2.weight"], P[f"{p}.linear2.bias"], epi=EPI_GATE_RES, res=h)
+            if self.fp8 and i in self._w8:
+                yq, ys = ops.quantize_rows_fp8(y.view(B * N, 4 * D))
+                h = ops.linear_fp8(yq, ys, *self._w8[i], P[f"{p}.linear2.bias"], epi=EPI_GATE_RES, res=h.view(B * N, D)).view(B, N, D)
+            else:
+                h = ops.linear(y, P[f"{p}.linear2.weight"], P[f"{p}.linear2.bias"], epi=EPI_GATE_RES, res=h)
             hs.append(h)
         last = ops.layernorm_affine(h, P["final_layer_norm.weight"], P["final_layer_norm.bias"])
         rows = (torch.arange(B, dtype=torch.int32) * N + eos.cpu().to(torch.int32)).to(self.device).contiguous()

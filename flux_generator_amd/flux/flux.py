@@ -56,6 +56,7 @@ class FluxPipeline:
         # T5-XXL / CLIP (~10 GB) are built on first use: under torchrun only rank 0 ever evaluates them
         # (parallel.shard_generation_inputs), so the other ranks never allocate or load them
         self._t5 = self._clip = None
+        self.text_fp8 = False        # quantize_text(): the towers are built lazily, the flag is applied when they are
         self.clip_tokenizer = load_clip_tokenizer(name)
         self.t5_tokenizer = load_t5_tokenizer(name)
         self.sampler = FluxSampler(name)
@@ -66,7 +67,7 @@ class FluxPipeline:
     @property
     def t5(self):
         if self._t5 is None:
-            self._t5 = load_t5(self.name, device=self.device)
+            self._t5 = load_t5(self.name, device=self.device).enable_fp8(self.text_fp8)
         return self._t5
 
     @t5.setter
@@ -76,7 +77,7 @@ class FluxPipeline:
     @property
     def clip(self):
         if self._clip is None:
-            self._clip = load_clip(self.name, device=self.device)
+            self._clip = load_clip(self.name, device=self.device).enable_fp8(self.text_fp8)
         return self._clip
 
     @clip.setter
@@ -91,10 +92,19 @@ class FluxPipeline:
             self.t5, self.clip      # noqa: B018  (build them now)
         torch.cuda.synchronize(self.device)
 
+    def quantize_text(self, enabled: bool = True) -> None:
+        """`--quantize` for the text towers (txt2image.py:79-82 quantises flow, t5 and clip): fp8 Linears in T5 (all but the
+        value projection) and in CLIP (the layers' second MLP Linear: the reference's in_dim % 512 predicate).  Applies to
+        towers already built and to the ones built later (they are lazy: rank 0 only under torchrun)."""
+        self.text_fp8 = bool(enabled)
+        for m in (self._t5, self._clip):
+            if m is not None:
+                m.enable_fp8(self.text_fp8)
+
     def reload_text_encoders(self):
         if self._encodes_text():
-            self._t5 = load_t5(self.name, device=self.device)
-            self._clip = load_clip(self.name, device=self.device)
+            self._t5 = load_t5(self.name, device=self.device).enable_fp8(self.text_fp8)
+            self._clip = load_clip(self.name, device=self.device).enable_fp8(self.text_fp8)
 
     # ------------------------------------------------------------------ captured graphs: bounded LRU
     def _graph_get(self, key):

@@ -98,6 +98,37 @@ class T5Encoder:
         self._params = {k: torch.empty(*v, dtype=BF16, device=self.device) for k, v in shp.items()}
         self._qk: Dict[int, torch.Tensor] = {}
         self._bias: Dict[int, torch.Tensor] = {}
+        self.fp8 = False
+        self._w8: Dict[str, tuple] = {}
+
+    def enable_fp8(self, enabled: bool = True) -> "T5Encoder":
+        """The reference's `--quantize` covers the text towers too (txt2image.py:79-82: nn.quantize of every Linear whose
+        in_dim % 512 == 0 - all of T5's).  Same redesign as the flow model's (include/fluxhip.h, fluxhip_gemm_fp8): OCP e4m3fn
+        weights with one float32 scale per output channel, inputs quantised per token on the fly, products on the block-scaled
+        fp8 MFMA; the [q;k] projection, out_proj and the three FFN Linears (98 % of the encoder's FLOPs).  The value
+        projection stays bf16: it is written transposed with the activations as the per-batch "weight" operand, which the fp8
+        entry point's per-batch scales do not describe.  RMSNorm, attention, residual stream: unchanged."""
+        if enabled and not self._w8:
+            if self.config.d_model % 128 or self.config.d_ff % 128:
+                raise ValueError("fp8 needs d_model % 128 == 0 and d_ff % 128 == 0")
+            P = self._params
+            for i in range(self.config.num_layers):
+                p = f"encoder.layers.{i}"
+                self._w8[f"{p}.qk"] = ops.quantize_rows_fp8(self._qk[i])
+                for n in ("attention.out_proj", "dense.wi_0", "dense.wi_1", "dense.wo"):
+                    self._w8[f"{p}.{n}"] = ops.quantize_rows_fp8(P[f"{p}.{n}.weight"])
+        self.fp8 = bool(enabled)
+        return self
+
+    def _lin(self, x: torch.Tensor, name: str, w: torch.Tensor, epi: int = ops.EPI_BIAS, res: Optional[torch.Tensor] = None):
+        """x @ w^T (+ epilogue): bf16, or per-token e4m3 x per-channel e4m3 when enable_fp8() is on."""
+        if not self.fp8:
+            return ops.linear(x, w, None, epi=epi, res=res)
+        K = x.shape[-1]
+        xq, xs = ops.quantize_rows_fp8(x.reshape(-1, K))
+        wq, ws = self._w8[name]
+        r2 = None if res is None else res.reshape(-1, res.shape[-1])
+        return ops.linear_fp8(xq, xs, wq, ws, None, epi=epi, res=r2).view(*x.shape[:-1], wq.shape[0])
 
     def parameters(self):
         return self._params
@@ -147,10 +178,13 @@ class T5Encoder:
 
     def finalize(self) -> "T5Encoder":
         P = self._params
+        was8, self._w8 = self.fp8, {}
         self._qk = {i: torch.cat([P[f"encoder.layers.{i}.attention.query_proj.weight"],
                                   P[f"encoder.layers.{i}.attention.key_proj.weight"]], dim=0).contiguous()
                     for i in range(self.config.num_layers)}
         self._bias = {}
+        if was8:
+            self.enable_fp8(True)           # new weights: quantise again
         return self
 
     def _position_bias(self, T: int) -> torch.Tensor:
@@ -184,15 +218,15 @@ class T5Encoder:
         for i in range(c.num_layers):
             p = f"encoder.layers.{i}"
             y = ops.rmsnorm(x, P[f"{p}.ln1.weight"], c.layer_norm_epsilon)
-            qk = ops.linear(y, self._qk[i])                                              # [B,T,2*inner]
+            qk = self._lin(y, f"{p}.qk", self._qk[i])                                    # [B,T,2*inner]
             ops.gemm(make_gemm_desc([dict(A=P[f"{p}.attention.value_proj.weight"].data_ptr(), W=y.data_ptr(),
                                           C=vt.data_ptr(), a_bstride=0, w_bstride=T * D, c_bstride=inner * Tpad, M=inner)],
                                     B, T, D, D, Tpad))
             st = (T * 2 * inner, 64, 2 * inner)
             ops.attention_masked(qk, qk[..., inner:], vt, o, B, H, T, T, Tpad, st, st, inner, 1.0, bias=bias)
-            x = ops.linear(o, P[f"{p}.attention.out_proj.weight"], epi=EPI_GATE_RES, res=x)
+            x = self._lin(o, f"{p}.attention.out_proj", P[f"{p}.attention.out_proj.weight"], EPI_GATE_RES, x)
             y = ops.rmsnorm(x, P[f"{p}.ln2.weight"], c.layer_norm_epsilon)
-            lin = ops.linear(y, P[f"{p}.dense.wi_1.weight"])
-            h = ops.linear(y, P[f"{p}.dense.wi_0.weight"], epi=EPI_GEGLU, res=lin)      # gelu(wi_0 y) * wi_1 y
-            x = ops.linear(h, P[f"{p}.dense.wo.weight"], epi=EPI_GATE_RES, res=x)
+            lin = self._lin(y, f"{p}.dense.wi_1", P[f"{p}.dense.wi_1.weight"])
+            h = self._lin(y, f"{p}.dense.wi_0", P[f"{p}.dense.wi_0.weight"], EPI_GEGLU, lin)      # gelu(wi_0 y) * wi_1 y
+            x = self._lin(h, f"{p}.dense.wo", P[f"{p}.dense.wo.weight"], EPI_GATE_RES, x)
         return ops.rmsnorm(x, P["encoder.ln.weight"], c.layer_norm_epsilon)

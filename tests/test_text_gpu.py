@@ -171,3 +171,58 @@ def test_clip_l_real_width_full_depth(dev):
     e, ep = rel_l2(got.last_hidden_state, ref.last_hidden_state), rel_l2(got.pooled_output, ref.pooled_output)
     print(f"CLIP-L full tower: last_hidden_state rel-L2 {e:.2e}, pooled {ep:.2e}")
     assert got.pooled_output.shape == (2, 768) and e < 1.5e-2 and ep < 1.5e-2
+
+
+def test_text_towers_fp8_quantize(dev):
+    """`--quantize` on the text towers (txt2image.py:79-82): T5 with e4m3 Linears (per-channel weights, per-token inputs; the
+    value projection stays bf16) against the text oracle on the DE-QUANTISED weights, and CLIP with its second MLP Linear
+    quantised (the only one passing the reference's in_dim % 512 predicate).  Bound as for the flow model's fp8 path: 6e-2."""
+    from flux_generator_amd import ops
+    from flux_generator_amd.flux.clip import CLIPTextModel, CLIPTextModelConfig
+    from flux_generator_amd.flux.t5 import T5Config, T5Encoder
+    kw = dict(vocab_size=200, num_layers=3, num_heads=4, relative_attention_num_buckets=32, d_kv=64, d_model=256,
+              feed_forward_proj="gated-gelu", tie_word_embeddings=False, d_ff=512)
+    ocfg = T.T5Config(**{k: v for k, v in kw.items() if k in T.T5Config.__dataclass_fields__})
+    W = {k: v.to(BF).float() for k, v in O.init_weights(T.t5_weight_shapes(ocfg), seed=0, norm_jitter=0.2).items()}
+    W["wte.weight"] = torch.randn(200, 256, generator=torch.Generator().manual_seed(1)).to(BF).float()
+    W["encoder.relative_attention_bias.embeddings.weight"] = torch.randn(32, 4, generator=torch.Generator().manual_seed(2)).to(BF).float()
+    model = T5Encoder(T5Config(**kw), device=dev).load_weights(W)
+    tokens = torch.randint(0, 200, (2, 40), generator=torch.Generator().manual_seed(3))
+    plain = model(tokens)
+    model.enable_fp8()
+    got = model(tokens)
+    assert model.fp8 and not torch.equal(got, plain)
+
+    def deq(name):
+        q, sc = model._w8[name]
+        return (q.view(torch.float8_e4m3fn).float() * sc.float()[:, None]).cpu()
+
+    Wd = dict(W)
+    for i in range(3):
+        p = f"encoder.layers.{i}"
+        qk = deq(f"{p}.qk")
+        Wd[f"{p}.attention.query_proj.weight"], Wd[f"{p}.attention.key_proj.weight"] = qk[:256], qk[256:]
+        for n in ("attention.out_proj", "dense.wi_0", "dense.wi_1", "dense.wo"):
+            Wd[f"{p}.{n}.weight"] = deq(f"{p}.{n}")
+    ref = T.t5_encoder(ocfg, Wd, tokens)
+    e = rel_l2(got, ref)
+    print(f"t5 fp8 vs oracle on de-quantised weights: {e:.2e}; vs the bf16 encoder: {rel_l2(got, plain.float().cpu()):.2e}")
+    assert e < 6e-2
+    model.enable_fp8(False)
+    assert torch.equal(model(tokens), plain)
+
+    ckw = dict(num_layers=2, model_dims=128, num_heads=2, max_length=77, vocab_size=300, hidden_act="quick_gelu")
+    ccfg = T.CLIPTextModelConfig(**ckw)
+    Wc = {k: v.to(BF).float() for k, v in O.init_weights(T.clip_weight_shapes(ccfg), seed=4, norm_jitter=0.2).items()}
+    for k in ("token_embedding.weight", "position_embedding.weight"):
+        Wc[k] = (torch.randn(Wc[k].shape, generator=torch.Generator().manual_seed(5)) * 0.5).to(BF).float()
+    clip = CLIPTextModel(CLIPTextModelConfig(**ckw), device=dev).load_weights(Wc).enable_fp8()
+    assert clip.fp8 and sorted(clip._w8) == [0, 1]           # in_dim 512 passes the predicate, width 128 does not
+    toks = torch.randint(1, 298, (2, 13), generator=torch.Generator().manual_seed(6))
+    toks[:, 0], toks[:, 12] = 298, 299
+    out = clip(toks)
+    for i in range(2):
+        q, sc = clip._w8[i]
+        Wc[f"layers.{i}.linear2.weight"] = (q.view(torch.float8_e4m3fn).float() * sc.float()[:, None]).cpu()
+    refc = T.clip_text_model(ccfg, Wc, toks)
+    assert rel_l2(out.last_hidden_state, refc.last_hidden_state) < 6e-2 and rel_l2(out.pooled_output, refc.pooled_output) < 6e-2

@@ -32,8 +32,9 @@ def build_parser():
     p.add_argument("--n-rows", type=int, default=1)
     p.add_argument("--decoding-batch-size", type=int, default=1)
     p.add_argument("--quantize", "-q", action="store_true",
-                   help="fp8 (e4m3) weights + per-token fp8 activations for the Linears of the flow transformer's blocks "
-                        "(99.6%% of the FLOPs) on the fp8 matrix cores; unlike the reference, T5 / CLIP stay bf16")
+                   help="fp8 (e4m3) weights + per-token fp8 activations on the fp8 matrix cores for the Linears of the flow "
+                        "transformer's blocks (99.6%% of its FLOPs), of the T5 encoder and of CLIP (the layers the reference's "
+                        "in_dim %% 512 predicate selects)")
     p.add_argument("--preload-models", action="store_true")
     p.add_argument("--output", default="out.png")
     p.add_argument("--save-raw", action="store_true")
@@ -84,8 +85,9 @@ def main(argv=None):
         # the reference's nn.quantize (txt2image.py:79-82) re-designed for CDNA4: e4m3 weights (per output channel) and
         # per-token e4m3 activations of the transformer blocks' Linears on the fp8 matrix cores
         flux.flow.enable_fp8()
-        print("--quantize: fp8 e4m3 on the flow transformer's block Linears only (T5 / CLIP / VAE keep their precision)",
-              file=sys.stderr)
+        flux.quantize_text()
+        print("--quantize: fp8 e4m3 Linears in the flow transformer's blocks, the T5 encoder (all but the value projection) and "
+              "CLIP (second MLP Linear: the reference's in_dim % 512 predicate); the VAE keeps float32", file=sys.stderr)
     if args.preload_models:
         flux.ensure_models_are_loaded()
 
