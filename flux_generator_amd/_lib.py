@@ -21,6 +21,7 @@ class GemmGroup(C.Structure):
         ("res", c_void_p), ("gate", c_void_p),
         ("a_bstride", c_int64), ("c_bstride", c_int64), ("gate_bstride", c_int64), ("w_bstride", c_int64),
         ("M", C.c_int32), ("_pad", C.c_int32),
+        ("add", c_void_p), ("add_bstride", c_int64),
     ]
 
 
@@ -35,6 +36,7 @@ class GemmDesc(C.Structure):
         ("C2", c_void_p), ("c2_bstride", c_int64),
         ("c2_coloff", C.c_int32), ("tile_cfg", C.c_int32),
         ("alpha", c_float), ("out_f32", C.c_int32),
+        ("ld_add", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 

@@ -523,6 +523,15 @@ static int params_from_desc(const fluxhip_gemm_desc* d, GemmParams& p, int kalig
     t.gate_bstride = s.gate_bstride;
     t.w_bstride = s.w_bstride;
     t.M = s.M;
+    t.addm = (const bf16_t*)s.add;
+    t.addm_bstride = s.add_bstride;
+    if ((s.add != nullptr) != (d->g[0].add != nullptr)) return FLUXHIP_EINVAL;     // all groups or none
+  }
+  if (d->g[0].add) {
+    if (d->ld_add < d->N || d->ld_add % 4 || d->row_bias || d->out_f32) return FLUXHIP_EINVAL;
+    p.addvec = (const bf16_t*)d->g[0].add;      // non-null: selects the addend epilogue; the kernel reads the group's matrix
+    p.addvec_rows = 1;
+    p.addvec_stride = d->ld_add;
   }
   if (d->epi == FLUXHIP_EPI_SPLIT_GELU && (!d->C2 || d->n_split % 4 || d->ldc2 % 4 || d->c2_coloff % 4))
     return FLUXHIP_EINVAL;
@@ -548,7 +557,7 @@ static int params_from_desc(const fluxhip_gemm_desc* d, GemmParams& p, int kalig
 // does launch() take the reduce-scatter kernel when this descriptor splits?  (what launch() tests: lean_ok && epi == rs_epi)
 static bool rs_epilogue(const fluxhip_gemm_desc* d) {
   auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-  bool ok = d->epi == FLUXHIP_EPI_GATE_RES && !d->row_bias && !d->out_f32 && d->N % 8 == 0 && d->ldc % 8 == 0;
+  bool ok = d->epi == FLUXHIP_EPI_GATE_RES && !d->g[0].add && !d->row_bias && !d->out_f32 && d->N % 8 == 0 && d->ldc % 8 == 0;
   for (int g = 0; g < d->ngroups && ok; ++g)
     ok = a16(d->g[g].C) && d->g[g].c_bstride % 8 == 0 && a16(d->g[g].res) && a16(d->g[g].gate) && d->g[g].gate_bstride % 8 == 0;
   return ok;

@@ -50,6 +50,8 @@ struct GemmGroup {
   long long w_bstride; // elements between batches of W (0: shared weight)
   int M;               // rows per batch
   int tiles_m;         // ceil(M / BM)
+  const bf16_t* addm;  // optional matrix addend [nbatch][M][addvec_stride] (GemmParams::addvec is then non-null as well)
+  long long addm_bstride;
 };
 
 struct ConvGeom {        // implicit-GEMM A loader (NHWC activations)
@@ -253,6 +255,8 @@ void gemm_nt_kernel(const GemmParams p) {
   bf16_t* gC = g1 ? p.g[1].C : p.g[0].C;
   const bf16_t* gRes = g1 ? p.g[1].res : p.g[0].res;
   const bf16_t* gGate = g1 ? p.g[1].gate : p.g[0].gate;
+  const bf16_t* gAddm = g1 ? p.g[1].addm : p.g[0].addm;
+  const long long addm_bs = g1 ? p.g[1].addm_bstride : p.g[0].addm_bstride;
   const long long a_bs = g1 ? p.g[1].a_bstride : p.g[0].a_bstride;
   const long long c_bs = g1 ? p.g[1].c_bstride : p.g[0].c_bstride;
   const long long gate_bs = g1 ? p.g[1].gate_bstride : p.g[0].gate_bstride;
@@ -1299,7 +1303,9 @@ void gemm_nt_kernel(const GemmParams p) {
     v[3] = acc[i][j][3] * alpha + (e_hi<F16>(bcol[j][1]) + brow[i]);
     }
     if constexpr (decltype(addvec_tag)::value) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
-      u32x2 aw = *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
+      // ... or a whole matrix addend of this group (the low-rank branch of an unfused LoRA layer): row m of batch b
+      u32x2 aw = gAddm ? *(const u32x2*)(gAddm + (long long)b * addm_bs + (long long)m * p.addvec_stride + n4)
+                       : *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
       v[0] = e_rnd<F16>(v[0]) + e_lo<F16>(aw[0]);
       v[1] = e_rnd<F16>(v[1]) + e_hi<F16>(aw[0]);
       v[2] = e_rnd<F16>(v[2]) + e_lo<F16>(aw[1]);

@@ -306,11 +306,12 @@ class FluxPipeline:
         return images        # under torchrun: this rank's images (self.shard); gather_images() collects them on rank 0
 
     def load_adapter(self, adapter_file: str, fuse: bool = False) -> int:
-        """txt2image.py:30-37 (`load_adapter`): read a LoRA adapter saved by the reference's dreambooth.py
-        (safetensors of `<layer>.lora_a` / `.lora_b` with metadata lora_rank / lora_blocks) and apply it to the flow
-        model.  The reference keeps LoRALinear layers unless --fuse-adapter folds them into the weights; the two are the
-        same function up to one bf16 rounding of W + BA, and inference here always runs on the folded weights (one
-        GEMM per layer at load time, none per step), so `fuse` only exists for signature compatibility."""
+        """txt2image.py:30-37 (`load_adapter`): read a LoRA adapter saved by the reference's dreambooth.py (safetensors of
+        `<layer>.lora_a` / `.lora_b` with metadata lora_rank / lora_blocks) and apply it to the flow model.  fuse=True
+        (`--fuse-adapter`): W <- W + (scale B^T A^T).astype(bf16), one GEMM per layer at load time, none per step
+        (LoRALinear.fuse, flux/lora.py:28-43).  fuse=False: the reference keeps LoRALinear layers, and so does this - the
+        low-rank branch stays separate and is added before the layer's activation / gate (`Flux.attach_lora`), so an update
+        below half a bf16 ulp of W is not rounded away."""
         from safetensors import safe_open
         weights = {}
         with safe_open(adapter_file, framework="pt") as f:
@@ -321,8 +322,10 @@ class FluxPipeline:
         for k, v in weights.items():
             if k.endswith(".lora_a") and rank and v.shape[1] != rank:
                 raise ValueError(f"{k}: rank {v.shape[1]} does not match the adapter's lora_rank {rank}")
-        # in place on the weight tensors: captured hipGraphs keep pointing at the (now updated) weights
-        return self.flow.fuse_lora(weights, scale=1.0)      # LoRALinear.from_base default scale (flux/lora.py:15)
+        if fuse:
+            # in place on the weight tensors: captured hipGraphs keep pointing at the (now updated) weights
+            return self.flow.fuse_lora(weights, scale=1.0)      # LoRALinear.from_base default scale (flux/lora.py:15)
+        return self.flow.attach_lora(weights, scale=1.0)          # (plan_epoch bump: stale step graphs are dropped)
 
     def generate(self, *args, **kwargs):
         """Alias of generate_images (BASELINE.json north_star wording)."""

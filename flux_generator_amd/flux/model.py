@@ -74,6 +74,8 @@ class Flux:
         self._ws: "OrderedDict[Tuple[int, int, int], dict]" = OrderedDict()   # per-(B, S, L) workspaces + launch plans, LRU
         self.fp8 = False             # enable_fp8(): e4m3 weights + per-token e4m3 activations on the fp8 matrix cores
         self._w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._lora: Dict[str, Tuple[torch.Tensor, torch.Tensor, float]] = {}   # attach_lora(): layer -> (A^T pad, B^T pad, scale)
+        self._lora_zero: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # ------------------------------------------------------------------ parameters
     def _alloc_parameters(self) -> None:
@@ -216,6 +218,8 @@ class Flux:
         token on the fly, and the products run on the block-scaled fp8 MFMA at twice the bf16 rate
         (include/fluxhip.h, fluxhip_gemm_fp8).  The residual stream, norms, modulation, attention and the small
         embedders stay bf16.  Weights are quantised once, here; launch plans are rebuilt."""
+        if enabled and self._lora:
+            raise ValueError("unfused LoRA branches run on the bf16 plan: fuse_lora the adapter before enable_fp8()")
         if enabled and not self._w8:
             for name, w in self._params.items():
                 if name.endswith(".weight") and name[: -len(".weight")].endswith(self._FP8_LAYERS) and w.dim() == 2:
@@ -256,6 +260,48 @@ class Flux:
             if n in self._w8:            # fp8 copy of this layer already made: requantise IN PLACE (launch plans hold its address)
                 ops.quantize_rows_fp8(W, out=self._w8[n][0], scale=self._w8[n][1])
         torch.cuda.synchronize(self.device)
+        return len(names)
+
+    LORA_PAD = 64        # the rank is zero-padded to one K-step of the GEMM (exact: the padding multiplies zeros)
+
+    def attach_lora(self, adapter: Dict[str, torch.Tensor], scale: float = 1.0) -> int:
+        """LoRA adapters kept as SEPARATE low-rank branches — what the reference runs when `--fuse-adapter` is absent
+        (flux/lora.py:73-76, LoRALinear.__call__):  y = linear(x) + (scale * ((x @ lora_a) @ lora_b)).astype(x.dtype).
+        Unlike `fuse_lora`, W is not touched, so an update smaller than half a bf16 ulp of W is not rounded away.  Per adapted
+        Linear the launch plan gets two skinny GEMMs (u = x A with the rank padded to 64 columns; z = scale * u B) and the
+        layer's own GEMM takes z as a matrix addend in its epilogue — before the fused activation / gate, where the reference
+        adds it (include/fluxhip.h, fluxhip_gemm_group.add).  Layers: the transformer blocks' Linears (what
+        FluxPipeline.linear_to_lora_layers adapts, flux/flux.py:229-239), incl. the modulation Linears?  No: those are
+        evaluated by the GEMV over the concatenated table; an adapter that targets them is refused here (use fuse_lora).
+        Returns the number of adapted layers; launch plans are rebuilt."""
+        names = sorted(k[: -len(".lora_a")] for k in adapter if k.endswith(".lora_a"))
+        for n in names:
+            if f"{n}.lora_b" not in adapter:
+                raise ValueError(f"adapter has {n}.lora_a but no {n}.lora_b")
+            if f"{n}.weight" not in self._params:
+                raise ValueError(f"adapter targets unknown layer {n}")
+            if n in self.mod_off or not n.endswith(self._FP8_LAYERS):
+                raise ValueError(f"{n}: only the blocks' qkv / proj / MLP / linear1 / linear2 Linears run an unfused branch; "
+                                 "fold this one with fuse_lora")
+        if self.fp8 and names:
+            raise ValueError("unfused LoRA branches run on the bf16 plan: enable_fp8(False) first, or fuse_lora")
+        lora = {}
+        for n in names:
+            W = self._params[f"{n}.weight"]
+            a, b = adapter[f"{n}.lora_a"], adapter[f"{n}.lora_b"]
+            out_d, in_d = W.shape
+            r = a.shape[1]
+            if tuple(a.shape) != (in_d, r) or tuple(b.shape) != (r, out_d) or r > self.LORA_PAD:
+                raise ValueError(f"Shape mismatch for {n}: lora_a {tuple(a.shape)}, lora_b {tuple(b.shape)}, weight {tuple(W.shape)} "
+                                 f"(rank <= {self.LORA_PAD})")
+            at = torch.zeros(self.LORA_PAD, in_d, dtype=BF16, device=self.device)     # rows = rank: the "weight" of u = x A
+            at[:r] = a.to(device=self.device, dtype=BF16).t()
+            bt = torch.zeros(out_d, self.LORA_PAD, dtype=BF16, device=self.device)    # [out, rank]: the "weight" of z = u B
+            bt[:, :r] = b.to(device=self.device, dtype=BF16).t()
+            lora[n] = (at, bt, float(scale))
+        self._lora = lora
+        self._ws.clear()
+        self.plan_epoch += 1
         return len(names)
 
     # ------------------------------------------------------------------ workspace + launch plan
@@ -303,6 +349,9 @@ class Flux:
             cat=buf(B, T, D + mlp), Q=buf(B, H, T, 128), K=buf(B, H, T, 128), Vt=buf(B, H, 128, Tpad),
             rope=buf(B, T, 64, 2), xl=buf(B, L, D), pred=buf(B, L, P.in_channels),
         )
+        if self._lora:  # unfused LoRA branches: u = x A [B, T, 64] and z = scale * u B [B, T, widest adapted output]
+            ws["lora_u"] = buf(B, T, self.LORA_PAD)
+            ws["lora_z"] = buf(B, T, max(self._params[f"{n}.weight"].shape[0] for n in self._lora))
         if self.fp8:   # one (e4m3 rows, per-token scale) scratch pair shared by every GEMM input of the step
             ws["a8"] = buf(B * T, D + mlp, dtype=torch.uint8)
             ws["asc"] = buf(B * T, dtype=torch.float32)
@@ -332,7 +381,35 @@ class Flux:
         forced = {tuple(int(v) for v in e.split("=")[0].split("x")): int(e.split("=")[1])
                   for e in os.environ.get("FLUXHIP_PLAN_TILES", "").split(",") if e}
 
-        def gemm(groups, nbatch, N, K, lda, ldc, epi=EPI_BIAS, **kw):
+        def gemm(groups, nbatch, N, K, lda, ldc, epi=EPI_BIAS, names=None, rows=None, **kw):
+            """names / rows: the layer name and first token row of every group - a launch whose layers carry an unfused LoRA
+            branch (attach_lora) is preceded by u = x A and z = scale * u B and takes z as its matrix addend."""
+            if names and any(n in self._lora for n in names):
+                U, Z, ldz, R = ptr["lora_u"], ptr["lora_z"], ws["lora_z"].shape[-1], self.LORA_PAD
+                ug, zg, scales = [], [], set()
+                for g, n, r0 in zip(groups, names, rows):
+                    if n in self._lora:
+                        at, bt, sc = self._lora[n]
+                        scales.add(sc)
+                    else:               # a stream of this launch without an adapter: a zero branch (z = 0 exactly)
+                        at = bt = None
+                    if at is None:
+                        key_ = ("zero", N, K)
+                        if key_ not in self._lora_zero:
+                            self._lora_zero[key_] = (torch.zeros(R, K, dtype=BF16, device=self.device),
+                                                     torch.zeros(N, R, dtype=BF16, device=self.device))
+                        at, bt = self._lora_zero[key_]
+                    ug.append(dict(A=g["A"], W=at.data_ptr(), C=U + r0 * R * e, a_bstride=g.get("a_bstride", 0), c_bstride=T * R, M=g["M"]))
+                    zg.append(dict(A=U + r0 * R * e, W=bt.data_ptr(), C=Z + r0 * ldz * e, a_bstride=T * R, c_bstride=T * ldz, M=g["M"]))
+                    g.update(add=Z + r0 * ldz * e, add_bstride=T * ldz)
+                if len(scales) > 1:
+                    raise ValueError("the adapters of one launch's streams must share their scale")
+                du = make_gemm_desc(ug, nbatch, R, K, lda, R)
+                dz = make_gemm_desc(zg, nbatch, N, R, R, ldz, alpha=scales.pop())
+                keep.extend([du, dz])
+                call(lib.fluxhip_gemm_bf16, ctypes.byref(du))
+                call(lib.fluxhip_gemm_bf16, ctypes.byref(dz))
+                kw["ld_add"] = ldz
             if (N, K) in forced:
                 kw["tile_cfg"] = forced[(N, K)]
             d = make_gemm_desc(groups, nbatch, N, K, lda, ldc, epi, **kw)
@@ -411,6 +488,11 @@ class Flux:
                 gs.append(g)
             return gs
 
+        def stream_names(wname, prefix):
+            """(layer names, first rows) of the groups two_streams builds."""
+            sel = [(f"{prefix}.{st}_{wname}", r0) for st, r0, M in (("txt", 0, S), ("img", S, L)) if M]
+            return dict(names=[n for n, _ in sel], rows=[r for _, r in sel])
+
         def two_streams8(src, K, C, ldc, c_bs, wname, N, epi=EPI_BIAS, res=None, gate_off=None, i_off=0, t_off=0, prefix=""):
             gs, wn = [], []
             for st, row0, M, moff in (("txt", 0, S, t_off), ("img", S, L, i_off)):
@@ -445,7 +527,8 @@ class Flux:
             if F8:
                 two_streams8(src, D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", 3 * D, prefix=p)
             else:
-                gemm(two_streams(ptr["xm"], D, T * D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", prefix=p), B, 3 * D, D, D, 3 * D)
+                gemm(two_streams(ptr["xm"], D, T * D, ptr["qkv"], 3 * D, T * 3 * D, "attn.qkv", prefix=p), B, 3 * D, D, D, 3 * D,
+                     **stream_names("attn.qkv", p))
             call(lib.fluxhip_qk_norm_rope_bf16, ptr["qkv"], 3 * D, B, T, S, H,
                  wo(f"{p}.txt_attn.norm.query_norm.weight"), wo(f"{p}.txt_attn.norm.key_norm.weight"),
                  w(f"{p}.img_attn.norm.query_norm.weight"), w(f"{p}.img_attn.norm.key_norm.weight"),
@@ -457,7 +540,7 @@ class Flux:
                              i_off=io, t_off=to, prefix=p)
             else:
                 gemm(two_streams(ptr["attn"], D, T * D, ptr["x"], D, T * D, "attn.proj", res=ptr["x"], gate_off=2 * D,
-                                 i_off=io, t_off=to, prefix=p), B, D, D, D, D, EPI_GATE_RES)
+                                 i_off=io, t_off=to, prefix=p), B, D, D, D, D, EPI_GATE_RES, **stream_names("attn.proj", p))
             src = ln_mod(mp + (to + 3 * D) * e, mp + (to + 4 * D) * e, mp + (io + 3 * D) * e, mp + (io + 4 * D) * e, S)
             if F8:
                 two_streams8(src, D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", mlp, EPI_GELU_TANH, prefix=p)
@@ -465,9 +548,9 @@ class Flux:
                              gate_off=5 * D, i_off=io, t_off=to, prefix=p)
             else:
                 gemm(two_streams(ptr["xm"], D, T * D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", prefix=p), B, mlp, D, D, mlp,
-                     EPI_GELU_TANH)
+                     EPI_GELU_TANH, **stream_names("mlp.layers.0", p))
                 gemm(two_streams(ptr["hmlp"], mlp, T * mlp, ptr["x"], D, T * D, "mlp.layers.2", res=ptr["x"], gate_off=5 * D,
-                                 i_off=io, t_off=to, prefix=p), B, D, mlp, mlp, D, EPI_GATE_RES)
+                                 i_off=io, t_off=to, prefix=p), B, D, mlp, mlp, D, EPI_GATE_RES, **stream_names("mlp.layers.2", p))
 
         for i in range(P.depth_single_blocks):                                # flux/layers.py:262-284
             p = f"single_blocks.{i}"
@@ -480,6 +563,7 @@ class Flux:
             else:
                 gemm([dict(A=ptr["xm"], W=w(f"{p}.linear1.weight"), bias=wo(f"{p}.linear1.bias"), C=ptr["qkv"],
                            a_bstride=T * D, c_bstride=T * 3 * D, M=T)], B, 3 * D + mlp, D, D, 3 * D, EPI_SPLIT_GELU,
+                     names=[f"{p}.linear1"], rows=[0],
                      n_split=3 * D, C2=ptr["cat"], ldc2=D + mlp, c2_bstride=T * (D + mlp), c2_coloff=D)
             call(lib.fluxhip_qk_norm_rope_bf16, ptr["qkv"], 3 * D, B, T, 0, H, None, None,
                  w(f"{p}.norm.query_norm.weight"), w(f"{p}.norm.key_norm.weight"),
@@ -493,7 +577,7 @@ class Flux:
             else:
                 gemm([dict(A=ptr["cat"], W=w(f"{p}.linear2.weight"), bias=wo(f"{p}.linear2.bias"), C=ptr["x"], res=ptr["x"],
                            gate=mp + (o + 2 * D) * e, gate_bstride=NM, a_bstride=T * (D + mlp), c_bstride=T * D, M=T)],
-                     B, D, D + mlp, D + mlp, D, EPI_GATE_RES)
+                     B, D, D + mlp, D + mlp, D, EPI_GATE_RES, names=[f"{p}.linear2"], rows=[0])
 
         # LastLayer on the img rows                                           flux/layers.py:298-302
         o = self.mod_off["final_layer.adaLN_modulation.layers.1"]

@@ -81,9 +81,10 @@ def gemm(desc: GemmDesc, f16: bool = False) -> None:
 
 def make_gemm_desc(groups: Sequence[dict], nbatch: int, N: int, K: int, lda: int, ldc: int, epi: int = EPI_BIAS,
                    n_split: int = 0, C2: Optional[int] = None, ldc2: int = 0, c2_bstride: int = 0,
-                   c2_coloff: int = 0, row_bias: bool = False, alpha: float = 1.0, tile_cfg: int = 0, out_f32: bool = False) -> GemmDesc:
+                   c2_coloff: int = 0, row_bias: bool = False, alpha: float = 1.0, tile_cfg: int = 0, out_f32: bool = False,
+                   ld_add: int = 0) -> GemmDesc:
     """groups: dicts of raw device addresses: A, W, bias, C, res, gate (ints or None) + a_bstride,
-    c_bstride, gate_bstride, M."""
+    c_bstride, gate_bstride, M; optionally add (+ add_bstride) with the desc's ld_add: a matrix addend."""
     d = GemmDesc()
     d.ngroups, d.nbatch, d.N, d.K, d.lda, d.ldc, d.epi = len(groups), nbatch, N, K, lda, ldc, epi
     d.row_bias, d.n_split, d.ldc2, d.C2, d.c2_bstride, d.c2_coloff = int(row_bias), n_split, ldc2, C2, c2_bstride, c2_coloff
@@ -95,6 +96,8 @@ def make_gemm_desc(groups: Sequence[dict], nbatch: int, N: int, K: int, lda: int
         t.a_bstride, t.c_bstride, t.gate_bstride = g.get("a_bstride", 0), g.get("c_bstride", 0), g.get("gate_bstride", 0)
         t.w_bstride = g.get("w_bstride", 0)
         t.M = g["M"]
+        t.add, t.add_bstride = g.get("add"), g.get("add_bstride", 0)
+    d.ld_add = ld_add
     return d
 
 

@@ -57,6 +57,9 @@ typedef struct fluxhip_gemm_group {
   int64_t w_bstride;     /* elements between batches of W (0 = one shared weight)         */
   int32_t M;             /* rows per batch                                                */
   int32_t _pad;
+  const void* add;       /* optional matrix addend [nbatch][M][ld_add] (16-bit storage type): C = epi(round16(A W^T + b) + add).
+                          * The low-rank branch of an UNFUSED LoRA layer, flux/lora.py:73-76: y + (scale * z).astype(x.dtype)  */
+  int64_t add_bstride;   /* elements between batches of add                               */
 } fluxhip_gemm_group;
 
 typedef struct fluxhip_gemm_desc {
@@ -75,6 +78,8 @@ typedef struct fluxhip_gemm_desc {
   int32_t tile_cfg;      /* 0 = auto; otherwise index into the compiled tile configs      */
   float alpha;           /* acc scale before bias (1.0 for Linear; 0 means 1.0)           */
   int32_t out_f32;       /* EPI_BIAS only: C is float32 [..][ldc] (VAE attention logits)  */
+  int32_t ld_add;        /* row stride (elements, multiple of 4) of the groups' `add` matrices; all groups or none carry one */
+  int32_t _pad2;
 } fluxhip_gemm_desc;
 
 /* Replaces nn.Linear (+ fused activation / gated residual) on the Flux path:

@@ -31,10 +31,11 @@ def test_loader_checks_abi_and_arch():
 
 
 def test_gemm_desc_layout_matches_header():
-    """sizeof/offsets of the ctypes mirror = the C struct (LP64): 2 x 88-byte groups + 72 bytes."""
+    """sizeof/offsets of the ctypes mirror = the C struct (LP64): 2 x 104-byte groups + 80 bytes."""
     from flux_generator_amd._lib import GemmDesc, GemmGroup
-    assert ctypes.sizeof(GemmGroup) == 88 and GemmGroup.M.offset == 80
-    assert ctypes.sizeof(GemmDesc) == 248 and GemmDesc.C2.offset == 216 and GemmDesc.alpha.offset == 240
+    assert ctypes.sizeof(GemmGroup) == 104 and GemmGroup.M.offset == 80 and GemmGroup.add.offset == 88
+    assert ctypes.sizeof(GemmDesc) == 288 and GemmDesc.C2.offset == 248 and GemmDesc.alpha.offset == 272
+    assert GemmDesc.ld_add.offset == 280
     from flux_generator_amd._lib import GemmX3Desc      # fluxhip_gemm_x3_desc: 5 pointers, 7 int64, 10 int32, float, pad
     assert ctypes.sizeof(GemmX3Desc) == 144 and GemmX3Desc.a_lo.offset == 40 and GemmX3Desc.M.offset == 96
     assert GemmX3Desc.alpha.offset == 136

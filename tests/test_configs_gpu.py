@@ -373,6 +373,92 @@ def test_sharded_pipeline_nccl_world1(dev, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------ LoRA adapters at inference
+def test_lora_adapter_unfused_branch(dev, tmp_path, monkeypatch):
+    """`--adapter` WITHOUT `--fuse-adapter`: the reference keeps LoRALinear layers, y = linear(x) + (scale (x A) B).astype(dtype)
+    (flux/lora.py:73-76).  Here: two skinny GEMMs per adapted Linear and the branch as a matrix addend of the layer's own
+    GEMM, before its fused activation / gate (Flux.attach_lora).
+      1. every kind of block Linear adapted, both streams of a double block, batch 2 (2-group launches with per-batch addends):
+         the forward matches the fp32 oracle evaluated with W + B^T A^T (in float32 the two forms are the same function);
+      2. the weights are untouched and a second attach replaces the first;
+      3. an adapter far below half a bf16 ulp of W: fuse_lora rounds it away (weights and prediction bit-unchanged), the
+         unfused branch keeps it - its effect on the prediction follows the oracle's."""
+    import warnings
+    from safetensors.torch import save_file
+    from flux_generator_amd.flux.flux import FluxPipeline
+    _tiny_flux_zoo(monkeypatch)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe = FluxPipeline("flux-schnell", device=str(dev))
+    flow = pipe.flow
+    P = flow.params
+    targets = ["single_blocks.1.linear1", "single_blocks.1.linear2", "single_blocks.0.linear2",
+               "double_blocks.1.img_attn.qkv", "double_blocks.1.txt_attn.qkv", "double_blocks.1.txt_attn.proj",
+               "double_blocks.1.img_mlp.layers.0", "double_blocks.1.txt_mlp.layers.2", "double_blocks.0.img_mlp.layers.2"]
+    g = torch.Generator().manual_seed(0)
+    before = {k: v.clone() for k, v in flow.parameters().items()}
+    adapter = {}
+    for n in targets:
+        out_d, in_d = before[f"{n}.weight"].shape
+        adapter[f"{n}.lora_a"] = (torch.randn(in_d, 8, generator=g) * in_d ** -0.5).to(BF)
+        adapter[f"{n}.lora_b"] = (torch.randn(8, out_d, generator=g) * 0.05).to(BF)
+    f = str(tmp_path / "final_adapters.safetensors")
+    save_file(adapter, f, metadata={"lora_rank": "8", "lora_blocks": "2"})
+    OP = O.FluxParams(in_channels=P.in_channels, vec_in_dim=P.vec_in_dim, context_in_dim=P.context_in_dim,
+                      hidden_size=P.hidden_size, mlp_ratio=P.mlp_ratio, num_heads=P.num_heads, depth=P.depth,
+                      depth_single_blocks=P.depth_single_blocks, axes_dim=P.axes_dim, theta=P.theta, qkv_bias=True,
+                      guidance_embed=False)
+    B = 2
+    z = torch.randn(B, 16, 16, 16, generator=g).to(BF)
+    img, ids = O.prepare_latent_images(z)
+    txt = (torch.randn(B, 32, P.context_in_dim, generator=g) * 0.5).to(BF)
+    tids = torch.zeros(B, 32, 3, dtype=torch.int32)
+    vec = torch.randn(B, P.vec_in_dim, generator=g).to(BF)
+    t = torch.full((B,), 0.5, dtype=BF)
+    args = [a.to(dev) for a in (img, ids, txt, tids, t, vec)]
+    base = flow(*args)
+
+    def oracle_with(ad, scale=1.0):
+        W = {k: v.float().cpu() for k, v in before.items()}
+        for n in {k[: -len(".lora_a")] for k in ad if k.endswith(".lora_a")}:
+            W[f"{n}.weight"] = W[f"{n}.weight"] + scale * (ad[f"{n}.lora_b"].float().t() @ ad[f"{n}.lora_a"].float().t())
+        return O.flux_forward(OP, W, img.float(), ids, txt.float(), tids, t, vec.float())
+
+    assert pipe.load_adapter(f, fuse=False) == len(targets)
+    got = flow(*args)
+    assert all(torch.equal(v, flow.parameters()[k]) for k, v in before.items()), "attach_lora must not touch the weights"
+    assert not torch.equal(got, base)
+    e = rel_l2(got, oracle_with(adapter))
+    print(f"unfused LoRA forward vs fp32 oracle with W + BA: {e:.2e}")
+    assert e < 1e-2
+    # the graph path of the pipeline picks up the rebuilt plan
+    xs = list(pipe._denoising_loop(args[0], args[1], args[2], args[3], args[5], num_steps=2))
+    assert bool(torch.isfinite(xs[-1]).all())
+    with pytest.raises(ValueError):
+        flow.attach_lora({"double_blocks.0.img_mod.lin.lora_a": torch.zeros(P.hidden_size, 8),
+                          "double_blocks.0.img_mod.lin.lora_b": torch.zeros(8, 6 * P.hidden_size)})
+    with pytest.raises(ValueError):
+        flow.enable_fp8()
+    # 3. a tiny adapter: |BA| ~ 1e-5 of a weight of magnitude ~ 0.05 (bf16 ulp there: 2.4e-4)
+    tiny = {k: (v.float() * (3e-3 if k.endswith(".lora_b") else 1.0)).to(BF) for k, v in adapter.items()}
+    assert flow.attach_lora(tiny) == len(targets)
+    small = flow(*args)
+    ref_base, ref_small = oracle_with({}), oracle_with(tiny)
+    d_ref, d_got = ref_small - ref_base, small.float().cpu() - base.float().cpu()
+    cos = float((d_ref * d_got).sum() / (d_ref.norm() * d_got.norm() + 1e-30))
+    print(f"tiny adapter: |d_ref| / |ref| = {float(d_ref.norm() / ref_base.norm()):.2e}, cosine(d_got, d_ref) = {cos:.3f}")
+    assert not torch.equal(small, base) and cos > 0.5, "the unfused branch lost a sub-ulp update"
+    assert flow.attach_lora({}) == 0                       # detach
+    assert torch.equal(flow(*args), base)
+    flow.fuse_lora(tiny)
+    changed = sum(int((flow.parameters()[f"{n}.weight"] != before[f"{n}.weight"]).sum()) for n in targets)
+    total = sum(before[f"{n}.weight"].numel() for n in targets)
+    fused = flow(*args)
+    d_fused = fused.float().cpu() - base.float().cpu()
+    cos_f = float((d_ref * d_fused).sum() / (d_ref.norm() * d_fused.norm() + 1e-30))
+    print(f"tiny adapter fused: {changed} of {total} weight elements moved, cosine(d_fused, d_ref) = {cos_f:.3f}")
+    assert changed < 0.3 * total and cos_f < cos, "folding a sub-ulp update into bf16 weights should lose most of it"
+
+
 def test_lora_adapter_fuse(dev, tmp_path, monkeypatch):
     """--adapter / --fuse-adapter (txt2image.py:30-37,76-77; flux/lora.py:28-43): an adapter file in the format the
     reference's dreambooth.py writes (`<layer>.lora_a` [in,r], `.lora_b` [r,out], metadata lora_rank / lora_blocks)

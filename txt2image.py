@@ -42,8 +42,8 @@ def build_parser():
     p.add_argument("--verbose", "-v", action="store_true")
     p.add_argument("--adapter")
     p.add_argument("--fuse-adapter", action="store_true",
-                   help="accepted for compatibility: adapters are always folded into the weights at load time "
-                        "(W + scale*B^T A^T, one bf16 rounding), inference never runs separate LoRA matmuls")
+                   help="fold the adapter into the weights at load time (W + scale*B^T A^T, one bf16 rounding); without it the "
+                        "low-rank branches stay separate, like the reference's LoRALinear layers")
     p.add_argument("--no-t5-padding", dest="t5_padding", action="store_false")
     return p
 
@@ -79,8 +79,9 @@ def main(argv=None):
     dev = flux.device
     if args.adapter:
         n = flux.load_adapter(args.adapter, fuse=args.fuse_adapter)
-        print(f"Applied LoRA adapter {args.adapter} to {n} layers (folded into the weights"
-              f"{'' if args.fuse_adapter else '; --fuse-adapter is implied in this build'})", file=sys.stderr)
+        print(f"Applied LoRA adapter {args.adapter} to {n} layers "
+              f"({'folded into the weights' if args.fuse_adapter else 'separate low-rank branches, like the unfused LoRALinear'})",
+              file=sys.stderr)
     if args.quantize:
         # the reference's nn.quantize (txt2image.py:79-82) re-designed for CDNA4: e4m3 weights (per output channel) and
         # per-token e4m3 activations of the transformer blocks' Linears on the fp8 matrix cores
