@@ -380,8 +380,8 @@ def test_lora_adapter_unfused_branch(dev, tmp_path, monkeypatch):
       1. every kind of block Linear adapted, both streams of a double block, batch 2 (2-group launches with per-batch addends):
          the forward matches the fp32 oracle evaluated with W + B^T A^T (in float32 the two forms are the same function);
       2. the weights are untouched and a second attach replaces the first;
-      3. an adapter far below half a bf16 ulp of W: fuse_lora rounds it away (weights and prediction bit-unchanged), the
-         unfused branch keeps it - its effect on the prediction follows the oracle's."""
+      3. an adapter far below half a bf16 ulp of W: fuse_lora rounds it away on most weight elements, the unfused branch
+         still carries (x A) B exactly (to bf16)."""
     import warnings
     from safetensors.torch import save_file
     from flux_generator_amd.flux.flux import FluxPipeline
@@ -438,25 +438,24 @@ def test_lora_adapter_unfused_branch(dev, tmp_path, monkeypatch):
                           "double_blocks.0.img_mod.lin.lora_b": torch.zeros(8, 6 * P.hidden_size)})
     with pytest.raises(ValueError):
         flow.enable_fp8()
-    # 3. a tiny adapter: |BA| ~ 1e-5 of a weight of magnitude ~ 0.05 (bf16 ulp there: 2.4e-4)
+    # 3. a tiny adapter: |BA| ~ 2e-5 where a bf16 ulp of W is 2.4e-4.  Folded, it is rounded away on most elements; kept
+    #    separate, the branch still carries it: z of the last adapted launch (single_blocks.1.linear2, whose input `cat` is
+    #    intact after the forward) equals (cat A) B.  (Its effect on the bf16 PREDICTION is below the output's own rounding.)
     tiny = {k: (v.float() * (3e-3 if k.endswith(".lora_b") else 1.0)).to(BF) for k, v in adapter.items()}
     assert flow.attach_lora(tiny) == len(targets)
-    small = flow(*args)
-    ref_base, ref_small = oracle_with({}), oracle_with(tiny)
-    d_ref, d_got = ref_small - ref_base, small.float().cpu() - base.float().cpu()
-    cos = float((d_ref * d_got).sum() / (d_ref.norm() * d_got.norm() + 1e-30))
-    print(f"tiny adapter: |d_ref| / |ref| = {float(d_ref.norm() / ref_base.norm()):.2e}, cosine(d_got, d_ref) = {cos:.3f}")
-    assert not torch.equal(small, base) and cos > 0.5, "the unfused branch lost a sub-ulp update"
+    flow(*args)
+    ws = flow._workspace(B, 32, img.shape[1])
+    n = "single_blocks.1.linear2"
+    zb = ws["lora_z"][..., : P.hidden_size].float().cpu()
+    want = (ws["cat"].float().cpu() @ tiny[f"{n}.lora_a"].float()) @ tiny[f"{n}.lora_b"].float()
+    assert float(want.abs().max()) > 0 and rel_l2(zb, want) < 1e-2, "the low-rank branch does not hold (x A) B"
     assert flow.attach_lora({}) == 0                       # detach
     assert torch.equal(flow(*args), base)
     flow.fuse_lora(tiny)
-    changed = sum(int((flow.parameters()[f"{n}.weight"] != before[f"{n}.weight"]).sum()) for n in targets)
-    total = sum(before[f"{n}.weight"].numel() for n in targets)
-    fused = flow(*args)
-    d_fused = fused.float().cpu() - base.float().cpu()
-    cos_f = float((d_ref * d_fused).sum() / (d_ref.norm() * d_fused.norm() + 1e-30))
-    print(f"tiny adapter fused: {changed} of {total} weight elements moved, cosine(d_fused, d_ref) = {cos_f:.3f}")
-    assert changed < 0.3 * total and cos_f < cos, "folding a sub-ulp update into bf16 weights should lose most of it"
+    changed = sum(int((flow.parameters()[f"{n_}.weight"] != before[f"{n_}.weight"]).sum()) for n_ in targets)
+    total = sum(before[f"{n_}.weight"].numel() for n_ in targets)
+    print(f"tiny adapter fused: {changed} of {total} weight elements moved at all")
+    assert changed < 0.3 * total, "folding a sub-ulp update into bf16 weights should lose most of it"
 
 
 def test_lora_adapter_fuse(dev, tmp_path, monkeypatch):
