@@ -72,6 +72,14 @@ def test_t5_encoder_tiny(dev):
     e = rel_l2(got, ref)
     print(f"t5 tiny rel-L2 {e:.2e}")
     assert got.shape == (2, 40, 256) and e < 1.5e-2
+    # the default path replays a captured hipGraph per (batch, length): same bits as the eager launches, also on a second
+    # prompt through the same graph
+    assert len(model._graphs) == 1
+    tokens2 = torch.randint(0, 200, (2, 40), generator=torch.Generator().manual_seed(4))
+    g2 = model(tokens2)
+    model.use_graph = False
+    assert torch.equal(model(tokens), got) and torch.equal(model(tokens2), g2) and not torch.equal(g2, got)
+    model.use_graph = True
     with pytest.raises(ValueError):
         T5Encoder(T5Config(**{**kw, "d_kv": 32}), device=dev)
 
