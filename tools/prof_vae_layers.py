@@ -4,6 +4,7 @@ import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import warnings; warnings.filterwarnings("ignore")
 import torch
+os.environ.setdefault("FLUX_ALLOW_RANDOM_INIT", "1")
 from flux_generator_amd import ops
 from flux_generator_amd.flux.utils import load_ae
 

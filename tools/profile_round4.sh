@@ -5,6 +5,7 @@
 #   attention kernels, the split-K phase trace, the norm-pass and attention-variant micro-benchmarks, and the bench JSON lines
 #   of the other configurations.  Everything lands in gpurun_out/; the summaries are copied to profiles/ by hand.
 set -u
+export FLUX_ALLOW_RANDOM_INIT=1      # the loaders random-initialise only on request (no checkpoints in this image)
 R=$(pwd)
 O=$R/gpurun_out
 mkdir -p $O
