@@ -250,11 +250,9 @@ def _parse_cpulist(text: str):
 def gpu_numa_node(index: int) -> int:
     """NUMA node of GPU `index` (its PCI function's sysfs `numa_node`), or -1 when the platform does not say."""
     try:
-        bus = torch.cuda.get_device_properties(index).pci_bus_id if hasattr(torch.cuda.get_device_properties(index), "pci_bus_id") else None
-        if bus is None:
-            p = torch.cuda.get_device_properties(index)
-            bus = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
-        with open(f"/sys/bus/pci/devices/{str(bus).lower()}/numa_node") as f:
+        p = torch.cuda.get_device_properties(index)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
             return int(f.read().strip())
     except Exception:
         return -1
