@@ -348,7 +348,8 @@ def main() -> None:
     dev = torch.device("cuda", torch.cuda.current_device())
     # N > 1: pin this rank's threads to its share of the CPUs of its GPU's NUMA node (8 ranks x graph launches + OpenMP pools)
     from flux_generator_amd import parallel as _par
-    placement = _par.bind_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), dev.index) if world > 1 else None
+    placement = (_par.bind_rank_to_cpus(int(os.environ.get("LOCAL_RANK", local_rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)), dev.index)
+                 if world > 1 else None)
     if placement and placement.get("cpus") and "OMP_NUM_THREADS" in os.environ:
         torch.set_num_threads(max(1, min(torch.get_num_threads(), int(placement["cpus"].split("(")[1].rstrip(")")))))
 
