@@ -55,6 +55,12 @@ class Fp8Scales(C.Structure):
     _fields_ = [("a_scale", c_void_p * 2), ("w_scale", c_void_p * 2), ("a_scale_bstride", c_int64)]
 
 
+class Fp8Mx(C.Structure):      # fluxhip_fp8_mx
+    _fields_ = [("a_mx", c_void_p), ("a_mx_row0", C.c_int32 * 2), ("a_mx_bstride", c_int64), ("a_mx_kstride", c_int64),
+                ("c8", c_void_p * 2), ("c8_bstride", c_int64), ("ldc8", C.c_int32), ("c8_coloff", C.c_int32),
+                ("c_mx", c_void_p), ("c_mx_row0", C.c_int32 * 2), ("c_mx_bstride", c_int64), ("c_mx_kstride", c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/fluxhip.h declares
 SIGNATURES = {
     "fluxhip_abi_version": (c_int, []),
@@ -108,6 +114,9 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "fluxhip_gemm_fp8": (c_int, [C.POINTER(GemmDesc), C.POINTER(Fp8Scales), c_void_p]),
     "fluxhip_gemm_fp8_tile_cfg": (c_int, [C.POINTER(GemmDesc)]),
+    "fluxhip_gemm_fp8_mx": (c_int, [C.POINTER(GemmDesc), C.POINTER(Fp8Scales), C.POINTER(Fp8Mx), c_void_p]),
+    "fluxhip_quantize_mx_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int64, c_int64,
+                                        c_void_p]),
     # fp32-faithful ("bf16x3") VAE path
     "fluxhip_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "fluxhip_join_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -169,7 +178,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fluxhip_abi_version() != 6 and not ab:
+    if lib.fluxhip_abi_version() != 7 and not ab:
         raise RuntimeError("libfluxhip ABI version mismatch")
     if lib.fluxhip_arch() != b"gfx950":
         raise RuntimeError("libfluxhip was not built for gfx950")

@@ -859,6 +859,56 @@ extern "C" int fluxhip_conv2d_small_x3(const void* x, int64_t x_lo, const void* 
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 
+// ---- block-scaled (MX) fp8 quantiser: e4m3 elements + one E8M0 scale per 32 consecutive columns, scale bytes in the tiled
+// layout the block-scaled GEMM reads (include/fluxhip.h).  A thread converts 8 columns, the 4 lanes of a quad share a block.
+// The arithmetic is the one of the FLAG_MXC GEMM epilogue (gemm_core.h): 2^e = smallest power of two with max|v| / 2^e <= 448.
+__global__ __launch_bounds__(256) void quantize_mx_fp8_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ out,
+                                                             uint8_t* __restrict__ mx, long long rows, int K, long long ld,
+                                                             long long ld_out, int col0, long long row0, long long kstride) {
+  const int cpr = K >> 3;                                  // 8-column chunks per row (a multiple of 4)
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long r = idx / cpr;
+  const int c = (int)(idx - r * cpr);
+  if (r >= rows) return;                                   // quad-uniform
+  const u32x4 w = *(const u32x4*)(x + r * ld + c * 8);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(w[e]); v[2 * e + 1] = bf_hi(w[e]); }
+  float am = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v[e]));
+  am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, am), 0xB1, 0xf, 0xf, true)));
+  am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, am), 0x4E, 0xf, 0xf, true)));
+  const uint32_t ab = __builtin_bit_cast(uint32_t, am);
+  int e8 = (int)(ab >> 23) - 8 + (int)((ab & 0x7fffffu) > 0x600000u);
+  e8 = min(max(e8, 1), 253);
+  const float mul = __builtin_bit_cast(float, (uint32_t)(254 - e8) << 23);
+  int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * mul, v[1] * mul, w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * mul, v[3] * mul, w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * mul, v[5] * mul, w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * mul, v[7] * mul, w1, true);
+  const int col = col0 + c * 8;
+  *(u32x2*)(out + r * ld_out + col) = u32x2{(uint32_t)w0, (uint32_t)w1};
+  if ((threadIdx.x & 3) == 0) {
+    const long long mrow = row0 + r;
+    const int kb = col >> 5;
+    mx[((((long long)(kb >> 2) * kstride + (mrow >> 6) * 64 + (kb & 3) * 16 + (mrow & 15)) << 2) + ((mrow >> 4) & 3))] = (uint8_t)e8;
+  }
+}
+
+extern "C" int fluxhip_quantize_mx_fp8(const void* x, void* out, void* mx, int64_t rows, int K, int64_t ld, int64_t ld_out,
+                                       int col0, int64_t row0, int64_t kstride, void* stream) {
+  if (!x || !out || !mx || rows < 1 || K < 32 || K % 32 || ld < K || ld % 8 || ld_out % 8 || col0 < 0 || col0 % 32 ||
+      ld_out < col0 + K || row0 < 0 || row0 % 64 || kstride % 64 || kstride < row0 + rows)
+    return FLUXHIP_EINVAL;
+  const long long n = rows * (long long)(K >> 3);
+  hipLaunchKernelGGL(quantize_mx_fp8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (uint8_t*)out, (uint8_t*)mx, (long long)rows, K, (long long)ld, (long long)ld_out, col0,
+                     (long long)row0, (long long)kstride);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
 // ---- fp8 row quantiser entry points ---------------------------------------------------------------
 extern "C" int fluxhip_quantize_rows_fp8(const void* x, void* out, void* scale, int64_t rows, int K, int64_t ld,
                                          void* stream) {

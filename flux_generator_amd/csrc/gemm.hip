@@ -18,6 +18,14 @@ FLUXHIP_TILES_X3(X)
 FLUXHIP_TILES_F8(X)
 #undef X
 
+// instantiated in gemm_mx.hip
+#define X(BM, BN, WM, WN, NS, PIPE) extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_FP8 | FLAG_LEAN | FLAG_MXA>(const GemmParams);
+FLUXHIP_TILES_MXA(X)
+#undef X
+#define X(BM, BN, WM, WN, NS, PIPE) extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_FP8 | FLAG_LEAN | FLAG_MXC>(const GemmParams);
+FLUXHIP_TILES_MXC(X)
+#undef X
+
 // instantiated in gemm_f16.hip / gemm_conv_f16.hip
 #define X(BM, BN, WM, WN, NS, PIPE) extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_F16>(const GemmParams);
 FLUXHIP_TILES_F16_DENSE(X)
@@ -43,6 +51,8 @@ struct TileCfg {
   void (*dense_rs)(const GemmParams) = nullptr;   // FLAG_RS | FLAG_LEAN (split-K reduce-scatter hand-off) variant: 256 x 256 / 256 x 192 ping-pong
   void (*dense_lean)(const GemmParams) = nullptr; // FLAG_LEAN: the same dense kernel with only the transformer-block epilogues compiled in (lean_ok)
   void (*dense_f8_lean)(const GemmParams) = nullptr;   // FLAG_FP8 | FLAG_LEAN: the four transformer-block epilogues (runtime switch)
+  void (*dense_f8_mxa)(const GemmParams) = nullptr;    // ... with a block-scaled activation operand (attached by shape below)
+  void (*dense_f8_mxc)(const GemmParams) = nullptr;    // ... with an e4m3 + block-scale output
   void (*dense_pair)(const GemmParams) = nullptr;      // FLAG_LEAN with EPI_GEGLU_PAIR compiled in (the UNet's fused GEGLU Linears)
   void (*dense_f16)(const GemmParams) = nullptr;       // FLAG_F16 (float16 storage) twins: the tiles of kCands / kConvCands
   void (*conv_f16)(const GemmParams) = nullptr;
@@ -163,13 +173,30 @@ TileCfg kCfgs[] = {
     with_pair<256, 256, 4, 2, 2, 6>(with_lean_f8<256, 256, 4, 2, 2, 6>(with_lean<256, 256, 4, 2, 2, 6, EPI_GELU_TANH>(with_rs<256, 256, 4, 2, 2, 6>(make_cfg_x3_f8<256, 256, 4, 2, 2, 6>())))),     // 49: cfg 43 with the ping-pong schedule (one MFMA-issuing wave per SIMD per phase)
     with_lean_f8<256, 224, 4, 2, 2, 6>(with_lean<256, 224, 4, 2, 2, 6, EPI_SPLIT_GELU>(make_cfg_f8<256, 224, 4, 2, 2, 6>())),     // 50: cfg 44 "
     with_lean<256, 192, 4, 2, 2, 6, EPI_BIAS>(with_rs<256, 192, 4, 2, 2, 6>(make_cfg_f8<256, 192, 4, 2, 2, 6>())),     // 51: cfg 45 "
-    make_cfg_f8<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
+    make_cfg_x3_f8<256, 128, 4, 2, 2, 6>(),     // 52: 256x128, ping-pong, 2 + 3 ring (112 KiB)
     make_cfg_f8<128, 128, 2, 4, 2, 6>(),     // 53: 128x128, ping-pong (80 KiB)
     make_cfg_f8<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
     with_pair<128, 256, 2, 4, 2, 6>(make_cfg_x3_f8<128, 256, 2, 4, 2, 6>()),     // 55: 128x256, ping-pong
     with_rs<256, 192, 4, 2, 2, 6, 1>(make_cfg<256, 192, 4, 2, 2, 6, 1>()),        // 56: cfg 51 with stamps around the main loop, the split-K reduce-scatter segments and the epilogue (diagnostic)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+// block-scaled fp8 twins, attached by tile shape (ping-pong tiles only)
+const bool g_mx_attached = [] {
+  auto attach = [](int bm, int bn, void (*k)(const GemmParams), bool mxa) {
+    for (int i = 49; i <= 55; ++i) {          // the ping-pong tiles
+      TileCfg& c = kCfgs[i];
+      if (c.bm == bm && c.bn == bn && c.dense_f8) (mxa ? c.dense_f8_mxa : c.dense_f8_mxc) = k;
+    }
+  };
+#define X(BM, BN, WM, WN, NS, PIPE) attach(BM, BN, gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_FP8 | FLAG_LEAN | FLAG_MXA>, true);
+  FLUXHIP_TILES_MXA(X)
+#undef X
+#define X(BM, BN, WM, WN, NS, PIPE) attach(BM, BN, gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_FP8 | FLAG_LEAN | FLAG_MXC>, false);
+  FLUXHIP_TILES_MXC(X)
+#undef X
+  return true;
+}();
 
 // float16-storage twins, attached by tile shape: a table entry gets the FLAG_F16 kernel of its own (BM, BN, waves, ring, PIPE)
 const bool g_f16_attached = [] {
@@ -192,7 +219,7 @@ const bool g_f16_attached = [] {
   return true;
 }();
 
-bool g_attr_set[kNumCfgs][12] = {};
+bool g_attr_set[kNumCfgs][14] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 
 // Tile choice: a time model per tile, fitted to tools/gemm_tune.py sweeps.
@@ -278,6 +305,10 @@ const Cand kF8Cands[] = {          // (t_step per 128-byte K-step, t_fixed) fitt
     {2, 2, 1.70f, 0.30f},  {3, 2, 1.35f, 2.90f},  {4, 2, 0.97f, 1.15f},
 };
 
+// block-scaled fp8 (FLAG_MXA / FLAG_MXC): the ping-pong tiles that carry those kernels, unsplit (rows of kF8Cands)
+const Cand kF8MxaCands[] = {{49, 1, 1.398f, 22.8f}, {50, 1, 1.460f, 13.2f}, {51, 1, 1.360f, 11.2f}, {52, 1, 1.137f, 11.1f}};
+const Cand kF8MxcCands[] = {{49, 1, 1.398f, 22.8f}, {51, 1, 1.360f, 11.2f}, {52, 1, 1.137f, 11.1f}};
+
 // Split-K workspace (fluxhip_set_workspace): [kSkMaxTiles] int32 hand-off counters (reduce-scatter mode: arrival counters
 // in the first half, departure counters in the second), then fp32 partial tiles.
 constexpr int kSkMaxTiles = 16384;
@@ -344,7 +375,7 @@ bool rs_ok(int cfg, int S, long long tiles, bool conv, bool x3, bool f8) {
 }
 
 // returns cfg | (splits << 8)
-template <int NC, bool RS = false>
+template <int NC, bool RS = false, int MAXS = 4>
 int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbatch, int N, int K,
               const CostForm& form = kPlainForm) {
   float best = 3.4e38f;
@@ -356,7 +387,7 @@ int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbat
     for (int g = 0; g < ngroups; ++g) tiles += (long long)((group_m[g] + t.bm - 1) / t.bm) * nbatch;
     tiles *= (N + t.bn - 1) / t.bn;
     const long long slots = 256LL * c.bpc;
-    for (int S = 1; S <= 4; ++S) {
+    for (int S = 1; S <= MAXS; ++S) {
       if (S > 1) {   // only under-filled grids with a long K loop, and only if the workspace can hold the partials
         if (c.bpc != 1 || tiles * S > slots || nkt / S < 16 || tiles > kSkMaxTiles) break;
         if (kSkFlagBytes + tiles * t.bm * t.bn * 4LL > g_ws_bytes) break;
@@ -379,7 +410,9 @@ int pick_from(const Cand (&cands)[NC], const int* group_m, int ngroups, int nbat
 // rs: the launch can take the reduce-scatter split-K kernels (lean-eligible gate-residual epilogue on bf16), so a split is
 // priced with the cheap hand-off; every other launch that splits runs the chain and is priced with it
 int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool conv = false, bool x3 = false,
-             bool f8 = false, bool rs = false) {
+             bool f8 = false, bool rs = false, int mx = 0) {
+  if (f8 && mx == 1) return pick_from<sizeof(kF8MxaCands) / sizeof(Cand), false, 1>(kF8MxaCands, group_m, ngroups, nbatch, N, K / 2);
+  if (f8 && mx == 2) return pick_from<sizeof(kF8MxcCands) / sizeof(Cand), false, 1>(kF8MxcCands, group_m, ngroups, nbatch, N, K / 2);
   if (f8) return pick_from(kF8Cands, group_m, ngroups, nbatch, N, K / 2);   // 128 elements per K-step
   if (x3)   // three passes over K
     return conv ? pick_from(kX3ConvCands, group_m, ngroups, nbatch, N, 3 * K)
@@ -389,7 +422,8 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
                    : pick_from(kCands, group_m, ngroups, nbatch, N, K, kDenseForm);
 }
 
-int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false, bool f8 = false, bool f16 = false) {
+// mx (fp8 only): 0 = per-token activation scales; 1 = block-scaled activation operand (FLAG_MXA); 2 = e4m3 + block-scale output (FLAG_MXC)
+int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false, bool f8 = false, bool f16 = false, int mx = 0) {
   int cfg_idx = cfg_code & 0xff;
   if (!conv && cfg_idx >= 49 && cfg_idx <= 56) {
     // the ping-pong tiles address their dense operands as scalar base + 32-bit byte offset per (group, batch); an
@@ -454,6 +488,12 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     if (conv || x3 || f8 || splits != 1 || !wide || p.addvec || p.row_bias || p.out_f32 || !c.dense_pair || p.N % 32) return FLUXHIP_EINVAL;
     if (f16 && !c.dense_pair_f16) return FLUXHIP_EINVAL;
     if (!(f16 ? use(c.dense_pair_f16, 11) : use(c.dense_pair, 8))) return FLUXHIP_ELAUNCH;
+  } else
+  if (mx) {                                       // block-scaled fp8: lean kernels of their own, no generic fallback
+    void (*const k)(const GemmParams) = mx == 1 ? c.dense_f8_mxa : c.dense_f8_mxc;
+    if (!f8 || !k || splits != 1 || !lean_any) return FLUXHIP_EINVAL;
+    if (mx == 2 && p.epi != EPI_GELU_TANH && p.epi != EPI_SPLIT_GELU) return FLUXHIP_EINVAL;
+    if (!use(k, 11 + mx)) return FLUXHIP_ELAUNCH;
   } else
   if (splits == 1 && lean_on) {
     bool ok = true;
@@ -596,6 +636,60 @@ extern "C" int fluxhip_gemm_fp8(const fluxhip_gemm_desc* d, const fluxhip_fp8_sc
   const int gm[2] = {d->g[0].M, d->ngroups > 1 ? d->g[1].M : 0};
   int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, d->ngroups, d->nbatch, d->N, d->K, false, false, true);
   return launch(p, cfg, false, (hipStream_t)stream, false, true);
+}
+
+// Block-scaled (MX) form: see include/fluxhip.h.
+extern "C" int fluxhip_gemm_fp8_mx(const fluxhip_gemm_desc* d, const fluxhip_fp8_scales* sc, const fluxhip_fp8_mx* mx, void* stream) {
+  GemmParams p{};
+  if (!sc || !mx) return FLUXHIP_EINVAL;
+  const bool mxa = mx->a_mx != nullptr, mxc = mx->c_mx != nullptr;
+  if (mxa == mxc) return FLUXHIP_EINVAL;          // one of the two per launch (the producer's own input comes out of LayerNorm: per token)
+  if (int rc = params_from_desc(d, p, 128)) return rc;
+  for (int g = 0; g < d->ngroups; ++g) {
+    if (!sc->w_scale[g] || (!mxa && !sc->a_scale[g])) return FLUXHIP_EINVAL;
+    if (d->g[g].M % 64) return FLUXHIP_EINVAL;    // whole 64-row groups of the scale tiling per wave
+    p.a_scale[g] = (const float*)sc->a_scale[g];
+    p.w_scale[g] = (const float*)sc->w_scale[g];
+  }
+  if (d->ngroups == 1) { p.a_scale[1] = p.a_scale[0]; p.w_scale[1] = p.w_scale[0]; }
+  p.a_sc_bstride = sc->a_scale_bstride;
+  const int ng = d->ngroups;
+  if (mxa) {
+    if (mx->a_mx_bstride % 64 || mx->a_mx_kstride % 64 || mx->a_mx_kstride <= 0 || ((uintptr_t)mx->a_mx & 3)) return FLUXHIP_EINVAL;
+    for (int g = 0; g < ng; ++g) {
+      if (mx->a_mx_row0[g] < 0 || mx->a_mx_row0[g] % 64) return FLUXHIP_EINVAL;
+      if (mx->a_mx_row0[g] + (d->nbatch - 1) * mx->a_mx_bstride + d->g[g].M > mx->a_mx_kstride) return FLUXHIP_EINVAL;
+      p.a_mx_row0[g] = mx->a_mx_row0[g];
+    }
+    if (ng == 1) p.a_mx_row0[1] = p.a_mx_row0[0];
+    if ((long long)(d->K / 128) * mx->a_mx_kstride * 4 >= (1ll << 32)) return FLUXHIP_EINVAL;   // 32-bit offsets in the K loop
+    p.a_mx = (const uint32_t*)mx->a_mx;
+    p.a_mx_bstride = mx->a_mx_bstride;
+    p.a_mx_kstride = mx->a_mx_kstride;
+  } else {
+    const bool split = d->epi == FLUXHIP_EPI_SPLIT_GELU;
+    if (d->epi != FLUXHIP_EPI_GELU_TANH && !split) return FLUXHIP_EINVAL;
+    if (d->N % 32 || mx->ldc8 % 8 || mx->c8_bstride % 8 || mx->c_mx_bstride % 64 || mx->c_mx_kstride % 64 || mx->c_mx_kstride <= 0)
+      return FLUXHIP_EINVAL;
+    if (split && (d->n_split % 32 || mx->c8_coloff % 32 || mx->c8_coloff < 0)) return FLUXHIP_EINVAL;
+    for (int g = 0; g < ng; ++g) {
+      if (!mx->c8[g] || ((uintptr_t)mx->c8[g] & 7) || mx->c_mx_row0[g] < 0 || mx->c_mx_row0[g] % 64) return FLUXHIP_EINVAL;
+      if (mx->c_mx_row0[g] + (d->nbatch - 1) * mx->c_mx_bstride + d->g[g].M > mx->c_mx_kstride) return FLUXHIP_EINVAL;
+      p.c8[g] = (uint8_t*)mx->c8[g];
+      p.c_mx_row0[g] = mx->c_mx_row0[g];
+    }
+    if (ng == 1) { p.c8[1] = p.c8[0]; p.c_mx_row0[1] = p.c_mx_row0[0]; }
+    p.c8_bstride = mx->c8_bstride;
+    p.ldc8 = mx->ldc8;
+    p.c8_coloff = split ? mx->c8_coloff : 0;
+    p.c_mx = (uint8_t*)mx->c_mx;
+    p.c_mx_bstride = mx->c_mx_bstride;
+    p.c_mx_kstride = mx->c_mx_kstride;
+  }
+  const int gm[2] = {d->g[0].M, ng > 1 ? d->g[1].M : 0};
+  const int mode = mxa ? 1 : 2;
+  const int cfg = d->tile_cfg > 0 ? d->tile_cfg : pick_cfg(gm, ng, d->nbatch, d->N, d->K, false, false, true, false, mode);
+  return launch(p, cfg, false, (hipStream_t)stream, false, true, false, mode);
 }
 
 extern "C" int fluxhip_gemm_fp8_tile_cfg(const fluxhip_gemm_desc* d) {

@@ -120,6 +120,23 @@ struct GemmParams {
   const float* a_scale[2];
   const float* w_scale[2];
   long long a_sc_bstride;
+  // FLAG_MXA kernels (fp8 with a block-scaled activation operand): E8M0 scale bytes of A, one per (row, 32 consecutive K
+  // elements), tiled so that lane (r16, q4) of a wave reads the bytes of its four 16-row fragments for one K-step as ONE
+  // dword (the block-scaled MFMA takes its scale from a byte of a per-lane register, op_sel picks the byte):
+  //     dword  ks * a_mx_kstride + (row >> 6) * 64 + q4 * 16 + (row & 15),   byte (row >> 4) & 3,
+  // q4 = K block inside the 128-element step ks, row = a_mx_row0[group] + batch * a_mx_bstride + m counted over the whole
+  // scale buffer (every term a multiple of 64).  a_scale is not read: the epilogue applies w_scale[n] only.
+  const uint32_t* a_mx;
+  int a_mx_row0[2];
+  long long a_mx_bstride, a_mx_kstride;
+  // FLAG_MXC kernels: the GELU'd output (EPI_GELU_TANH: every column; EPI_SPLIT_GELU: the columns from n_split on, at
+  // column n - n_split + c8_coloff) leaves as e4m3 bytes [M][ldc8] + block scales in the tiling above - the next GEMM's A.
+  uint8_t* c8[2];
+  long long c8_bstride;
+  int ldc8, c8_coloff;
+  uint8_t* c_mx;
+  int c_mx_row0[2];
+  long long c_mx_bstride, c_mx_kstride;
 };
 
 enum GemmFlags : int {
@@ -148,6 +165,14 @@ enum GemmFlags : int {
   // float16 storage (the stable_diffusion/ path with float16=True, the reference's flux_app.py:77-79): operands, bias,
   // residual, gate, addvec and outputs are IEEE half; v_mfma_f32_16x16x32_f16 issues at the bf16 rate; accumulation stays fp32
   FLAG_F16 = 64,
+  // fp8 with MX-style block scales (OCP e4m3 elements, one E8M0 scale per 32 consecutive K elements of a row), so that a
+  // producer's epilogue can quantise its own output tile (a per-token scale needs the whole row).  FLAG_MXA: the activation
+  // operand carries block scales, fed to the MFMA's scale operand (GemmParams::a_mx); FLAG_MXC: the epilogue writes e4m3 +
+  // block scales instead of bf16 (GemmParams::c8 / c_mx).  Ping-pong fp8 lean kernels only.  (tools/probes/mfma_mx_probe*.hip:
+  // the scale byte of lane (r, kb) scales k in [32 kb, 32 kb + 32) of row r, and the instruction's own K order is the one
+  // the fp8 loop already uses - lane group kb supplies the 16-byte chunks kb and 4 + kb - so memory K order = MFMA K order.)
+  FLAG_MXA = 8,
+  FLAG_MXC = 128,
   FLAG_LEAN = 32,    // dense bf16 only: the epilogues, operands and hand-offs the Flux / transformer-block launches use, nothing else compiled in (see gemm.hip lean_ok)
 };
 
@@ -281,6 +306,8 @@ void gemm_nt_kernel(const GemmParams p) {
   constexpr int ESZ = F8 ? 1 : 2;                  // bytes per operand element
   static_assert(!(F8 && (X3 || AMODE != 0)), "fp8: dense operands, no split mode");
   static_assert(!F8 || PIPE == 0 || PIPE == 6, "fp8 variants exist for the simple ring and the ping-pong schedule");
+  constexpr bool MXA = (FLAGS & FLAG_MXA) != 0, MXC = (FLAGS & FLAG_MXC) != 0;
+  static_assert(!(MXA || MXC) || (F8 && PIPE == 6 && (FLAGS & FLAG_LEAN) != 0), "block-scaled fp8: lean ping-pong kernels");
   const int nkt_all = X3 ? 3 * (K / BK) : K / (BK * 2 / ESZ);
   // K range of this block (even split; skewing the ranges so that the producer finishes early did not
   // pay: the release fence of the early block slows the L2 for the blocks still in their main loop)
@@ -615,8 +642,31 @@ void gemm_nt_kernel(const GemmParams p) {
           read_frags(a1, w1, slot_a, slot_w, 1);
         }
       };
+      // FLAG_MXA: the block scales of this wave's 64 rows for one K-step are one dword per lane (byte i = fragment i), fetched
+      // a step ahead by an untracked (inline-asm) global load that the loops' own vmcnt waits cover: issued BEFORE the LDS-DMA
+      // pieces of the same phase, so every counted wait that lands those pieces lands it too.  sc_cur feeds the MFMAs of the
+      // current step, sc_nxt is in flight / landed for the next one.
+      static_assert(!MXA || MI == 4, "block-scaled A: 64-row wave tiles (one scale byte per fragment in a dword)");
+      uint32_t sc_cur = 0x7f7f7f7fu, sc_nxt = 0x7f7f7f7fu, mx_off = 0;
+      if constexpr (MXA) {
+        const int rowb = (g1 ? p.a_mx_row0[1] : p.a_mx_row0[0]) + b * (int)p.a_mx_bstride + min(m0 + wm * WTM, Mg - WTM);
+        mx_off = (uint32_t)(((long long)kbase * p.a_mx_kstride + rowb + lane) * 4);     // < 4 GiB: checked by the launcher
+      }
+      const uint32_t mx_step = MXA ? (uint32_t)(p.a_mx_kstride * 4) : 0u;
+      auto mx_load = [&](uint32_t& dst) {        // scales of the next K-step not yet requested
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(mx_off), "s"(p.a_mx) : "memory");
+        mx_off += mx_step;
+      };
       auto mma_both = [&]() {
-        if constexpr (F8) {
+        if constexpr (F8 && MXA) {
+          static_for<0, MI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(W8[j], A8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, i,
+                                                                           (int)sc_cur);
+          });
+        } else if constexpr (F8) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -724,6 +774,10 @@ void gemm_nt_kernel(const GemmParams p) {
             wait_vmcnt<0>();
           }
         } else {
+        if constexpr (MXA) {                       // scales of steps 0 and 1: older than every piece below
+          mx_load(sc_cur);
+          if (nkt > 1) mx_load(sc_nxt);
+        }
         stage(0, 0);
         if (nkt > 1) {
           stage(1, 1);
@@ -733,6 +787,7 @@ void gemm_nt_kernel(const GemmParams p) {
         }
         }
         __builtin_amdgcn_s_barrier();
+        if constexpr (MXA) asm volatile("" : "+v"(sc_cur));       // landed (the wait above): readable from here on
         read_both(REUSE_HI ? (pk == 2) : 0, 0);
         int sa = REUSE_HI ? (pk == 2) : 0, sw = 0; // ring slots of step kt
         if constexpr (F8) {
@@ -749,8 +804,15 @@ void gemm_nt_kernel(const GemmParams p) {
             const int sprev = sa;
             sa ^= 1;
             sw = sw == 2 ? 0 : sw + 1;
+            if constexpr (MXA) {                   // scales of step kt: landed at the wait_vmcnt<0> that closed the previous trip
+              asm volatile("" : "+v"(sc_nxt));
+              sc_cur = sc_nxt;
+            }
             read_both(sa, sw);                     // memory phase of step kt - 1: fragments of step kt ...
-            if (kt + 1 < nkt) stage(kt + 1, sprev);   // ... and A(kt + 1) into the slot step kt - 1 has drained
+            if (kt + 1 < nkt) {
+              if constexpr (MXA) mx_load(sc_nxt);   // scales of step kt + 1
+              stage(kt + 1, sprev);                // ... and A(kt + 1) into the slot step kt - 1 has drained
+            }
             __builtin_amdgcn_s_barrier();          // B2 of step kt - 1
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -811,6 +873,7 @@ void gemm_nt_kernel(const GemmParams p) {
             glds16(wbase + koff + (size_t)wo, smem + W_BASE + slot * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
           }
         };
+        if constexpr (MXA) mx_load(sc_cur);        // scales of step 0: older than every piece below
         stage(0, 0);
         if (nkt > 1) {
           stage(1, 1);
@@ -819,12 +882,14 @@ void gemm_nt_kernel(const GemmParams p) {
           wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
+        if constexpr (MXA) asm volatile("" : "+v"(sc_cur));
         int sa = 0, sw = 0;
         int pk = X3 ? kbase % 3 : 0;               // FLAG_SPLIT: the activation slot of a step is its pass (see group 0)
         for (int kt = 0; kt < nkt; ++kt) {
           const int sw1 = sw == 2 ? 0 : sw + 1, sw2 = sw1 == 2 ? 0 : sw1 + 1;
           if constexpr (X3) sa = pk == 2;
           read_both(sa, sw);
+          if constexpr (MXA) { if (kt + 1 < nkt) mx_load(sc_nxt); }   // scales of step kt + 1, ahead of W(kt + 2): the wait below lands them
           if (kt + 2 < nkt) {
             stage(kt + 2, sw2);
             wait_vmcnt<PB>();                      // W(kt+1) landed; W(kt+2) may still fly
@@ -837,6 +902,10 @@ void gemm_nt_kernel(const GemmParams p) {
           mma_both();
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();            // B2
+          if constexpr (MXA) {
+            asm volatile("" : "+v"(sc_nxt));
+            sc_cur = sc_nxt;
+          }
           sa ^= 1;
           sw = sw1;
           if constexpr (X3) pk = pk == 2 ? 0 : pk + 1;
@@ -1285,7 +1354,7 @@ void gemm_nt_kernel(const GemmParams p) {
     const float* as_ = (g1 ? p.a_scale[1] : p.a_scale[0]) + (long long)b * p.a_sc_bstride;
     const float* ws_ = g1 ? p.w_scale[1] : p.w_scale[0];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) asc[i] = as_[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)] * alpha;
+    for (int i = 0; i < MI; ++i) asc[i] = MXA ? alpha : as_[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)] * alpha;   // MXA: the MFMA applied the block scales
 #pragma unroll
     for (int j = 0; j < NJ; ++j) wsc[j] = *(const f32x4*)(ws_ + min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4));
   }
@@ -1435,6 +1504,40 @@ void gemm_nt_kernel(const GemmParams p) {
       const int m = m0 + wm * WTM + row, n8 = n0 + wn * WTN + c * 8;
       if (row >= WTM || m >= Mg || n8 >= N) continue;
       const u32x4 x = *(const u32x4*)(my_lds + row * (NCH * 16) + cswz(c, row) * 16);
+      if constexpr (MXC) {
+        // FLAG_MXC: GELU, then e4m3 with one E8M0 scale per 32 consecutive columns = the 4 lanes of a quad (idx, n8 and the
+        // tests above are quad-uniform: N, n_split and the column offsets are multiples of 32).  Scale 2^e, e the smallest
+        // exponent with max|v| / 2^e <= 448 (the e4m3 maximum): no element saturates, the conversion rounds to nearest even.
+        const bool gelu_half = epi == EPI_GELU_TANH || (epi == EPI_SPLIT_GELU && n8 >= p.n_split);
+        if (gelu_half) {
+          static_assert(!MXC || (NCH % 4 == 0 && WTN % 32 == 0 && BN % 32 == 0), "block-scaled output: 32-column blocks inside a wave's sub-tile");
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[2 * r] = gelu_tanh_f(e_lo<F16>(x[r])); v[2 * r + 1] = gelu_tanh_f(e_hi<F16>(x[r])); }
+          float am = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) am = fmaxf(am, fabsf(v[r]));
+          am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, am), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+          am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, am), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+          const uint32_t ab = __builtin_bit_cast(uint32_t, am);
+          int e8 = (int)(ab >> 23) - 8 + (int)((ab & 0x7fffffu) > 0x600000u);      // 448 = 1.75 * 2^8
+          e8 = min(max(e8, 1), 253);
+          const float mul = __builtin_bit_cast(float, (uint32_t)(254 - e8) << 23);   // 2^(127 - e8)
+          int w0 = 0, w1 = 0;
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * mul, v[1] * mul, w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * mul, v[3] * mul, w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * mul, v[5] * mul, w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * mul, v[7] * mul, w1, true);
+          const int col = epi == EPI_SPLIT_GELU ? n8 - p.n_split + p.c8_coloff : n8;
+          *(u32x2*)((g1 ? p.c8[1] : p.c8[0]) + (long long)b * p.c8_bstride + (long long)m * p.ldc8 + col) = u32x2{(uint32_t)w0, (uint32_t)w1};
+          if ((lane & 3) == 0) {
+            const long long mrow = (g1 ? p.c_mx_row0[1] : p.c_mx_row0[0]) + (long long)b * p.c_mx_bstride + m;
+            const int kb = col >> 5;
+            p.c_mx[((((long long)(kb >> 2) * p.c_mx_kstride + (mrow >> 6) * 64 + (kb & 3) * 16 + (mrow & 15)) << 2) + ((mrow >> 4) & 3))] = (uint8_t)e8;
+          }
+          continue;
+        }
+      }
       bf16_t* dst;
       u32x4 o = x;
       if (epi != EPI_BIAS) {

@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import Fp8Scales, GemmDesc, GemmX3Desc
+from ._lib import Fp8Mx, Fp8Scales, GemmDesc, GemmX3Desc
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GATE_RES, EPI_SPLIT_GELU, EPI_SILU, EPI_GEGLU, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_GEGLU_PAIR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 BF16 = torch.bfloat16
@@ -373,6 +373,84 @@ def linear_fp8(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scal
     g = dict(A=_p(xq), W=_p(wq), bias=_p(b), C=_p(out), res=_p(res), gate=_p(gate), M=M)
     gemm_fp8(make_gemm_desc([g], 1, N, K, K, N, epi, tile_cfg=tile_cfg), make_fp8_scales([_p(x_scale)], [_p(w_scale)]))
     return out
+
+
+# block-scaled ("MX") fp8: e4m3 elements + one E8M0 scale per 32 consecutive columns, scale bytes tiled for the GEMM's K loop
+# (include/fluxhip.h, fluxhip_fp8_mx)
+def mx_scale_buffer(rows: int, K: int, device) -> torch.Tensor:
+    """Scale buffer for an [rows, K] e4m3 matrix: uint8 [(K / 128) * rows * 4]; rows % 64 == 0, K % 128 == 0."""
+    if rows % 64 or K % 128:
+        raise FluxHipError("block-scale buffers cover whole 64-row groups and 128-element K-steps")
+    return torch.full(((K // 128) * rows * 4,), 127, dtype=torch.uint8, device=device)
+
+
+def mx_scale_index(rows_idx: torch.Tensor, kb: torch.Tensor, kstride: int) -> torch.Tensor:
+    """Byte offset of the scale of (scale-buffer row, 32-column block kb) in the tiled layout."""
+    return ((((kb >> 2) * kstride + (rows_idx >> 6) * 64 + (kb & 3) * 16 + (rows_idx & 15)) << 2) + ((rows_idx >> 4) & 3))
+
+
+def quantize_mx_fp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, mx: Optional[torch.Tensor] = None, col0: int = 0,
+                    row0: int = 0, kstride: Optional[int] = None):
+    """x bf16 [rows, K] -> (q uint8 e4m3 [rows, ld_out] written at columns [col0, col0 + K), tiled E8M0 scale bytes)."""
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != BF16:
+        raise FluxHipError("quantize_mx_fp8 takes a 2-D bf16 tensor with contiguous rows")
+    rows, K = x.shape
+    if out is None:
+        out = torch.empty(rows, col0 + K, dtype=torch.uint8, device=x.device)
+    if kstride is None:
+        kstride = row0 + rows
+    if mx is None:
+        mx = mx_scale_buffer(kstride, out.shape[1], x.device)
+    _check(_lib.load().fluxhip_quantize_mx_fp8(_p(x), _p(out), _p(mx), rows, K, x.stride(0), out.stride(0), col0, row0, kstride,
+                                               _stream()), "fluxhip_quantize_mx_fp8")
+    return out, mx
+
+
+def make_fp8_mx(a_mx=None, a_row0=(0, 0), a_bstride=0, a_kstride=0, c8=None, c8_bstride=0, ldc8=0, c8_coloff=0, c_mx=None,
+                c_row0=(0, 0), c_bstride=0, c_kstride=0) -> Fp8Mx:
+    """Raw device addresses: consumer form (a_mx ...) or producer form (c8 per group, c_mx ...)."""
+    m = Fp8Mx()
+    m.a_mx, m.a_mx_bstride, m.a_mx_kstride = a_mx, a_bstride, a_kstride
+    m.c_mx, m.c_mx_bstride, m.c_mx_kstride = c_mx, c_bstride, c_kstride
+    m.c8_bstride, m.ldc8, m.c8_coloff = c8_bstride, ldc8, c8_coloff
+    for i in range(2):
+        m.a_mx_row0[i] = a_row0[min(i, len(a_row0) - 1)]
+        m.c_mx_row0[i] = c_row0[min(i, len(c_row0) - 1)]
+    for i, c in enumerate(c8 or ()):
+        m.c8[i] = c
+    return m
+
+
+def gemm_fp8_mx(desc: GemmDesc, scales: Fp8Scales, mx: Fp8Mx) -> None:
+    _check(_lib.load().fluxhip_gemm_fp8_mx(desc, scales, mx, _stream()), "fluxhip_gemm_fp8_mx")
+
+
+def linear_fp8_mxa(xq: torch.Tensor, x_mx: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
+                   b: Optional[torch.Tensor] = None, epi: int = EPI_BIAS, out: Optional[torch.Tensor] = None,
+                   res: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, tile_cfg: int = 0) -> torch.Tensor:
+    """y = epi(dequant_mx(xq, x_mx) @ (wq * w_scale[:, None]).T + b): block-scaled activation operand; y bf16."""
+    M, K = xq.shape
+    N = wq.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=xq.device)
+    g = dict(A=_p(xq), W=_p(wq), bias=_p(b), C=_p(out), res=_p(res), gate=_p(gate), M=M)
+    gemm_fp8_mx(make_gemm_desc([g], 1, N, K, xq.stride(0), N, epi, tile_cfg=tile_cfg), make_fp8_scales([None], [_p(w_scale)]),
+                make_fp8_mx(a_mx=_p(x_mx), a_kstride=M))
+    return out
+
+
+def linear_fp8_gelu_mxc(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
+                        b: Optional[torch.Tensor] = None, tile_cfg: int = 0):
+    """(q, mx) = quantize_mx(gelu_tanh((xq * x_scale) @ (wq * w_scale).T + b)): the quantisation runs in the GEMM's epilogue."""
+    M, K = xq.shape
+    N = wq.shape[0]
+    q = torch.empty(M, N, dtype=torch.uint8, device=xq.device)
+    mx = mx_scale_buffer(M, N, xq.device)
+    dummy = torch.empty(8, dtype=BF16, device=xq.device)      # C is not written by the all-GELU form
+    g = dict(A=_p(xq), W=_p(wq), bias=_p(b), C=_p(dummy), M=M)
+    gemm_fp8_mx(make_gemm_desc([g], 1, N, K, K, N, EPI_GELU_TANH, tile_cfg=tile_cfg), make_fp8_scales([_p(x_scale)], [_p(w_scale)]),
+                make_fp8_mx(c8=[_p(q)], ldc8=N, c_mx=_p(mx), c_kstride=M))
+    return q, mx
 
 
 # ------------------------------------------------------------------------------------------------ fp32-faithful VAE path

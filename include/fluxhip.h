@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define FLUXHIP_ABI_VERSION 6
+#define FLUXHIP_ABI_VERSION 7
 
 int fluxhip_abi_version(void);
 /* "gfx950" — the only architecture this library is built for. */
@@ -371,6 +371,41 @@ typedef struct fluxhip_fp8_scales {
  * lda % 16 == 0); bias / C / res / gate / C2 stay bf16. */
 int fluxhip_gemm_fp8(const fluxhip_gemm_desc* d, const fluxhip_fp8_scales* sc, void* stream);
 int fluxhip_gemm_fp8_tile_cfg(const fluxhip_gemm_desc* d);
+
+/* ---- block-scaled ("MX") fp8: quantisation fused into the producing kernel ---------------------------------------
+ * A per-token scale needs the whole row before the first byte can be written, which forces a stand-alone quantise pass
+ * between a producer (GELU epilogue, attention) and the next Linear.  With one power-of-two scale per 32 consecutive
+ * elements of a row (OCP MX: e4m3 elements, E8M0 scales = biased exponent bytes, value 2^(byte - 127)) a producer can
+ * quantise the tile it holds, and v_mfma_scale_f32_16x16x128_f8f6f4 applies the scales itself.
+ * Block scale of 32 values: the smallest power of two 2^e with max|v| / 2^e <= 448; elements = RNE(v / 2^e) in e4m3fn
+ * (nothing saturates); an all-zero block gets byte 1.
+ * Scale bytes are stored TILED so that one lane of the GEMM reads the four bytes it needs for a 128-element K-step as one
+ * dword: with `row` counted over the whole scale buffer (row0 of the group + batch * bstride + m; row0, bstride and
+ * kstride multiples of 64, kstride >= the buffer's row count) and kb = column / 32,
+ *     byte offset = (((kb >> 2) * kstride + (row >> 6) * 64 + (kb & 3) * 16 + (row & 15)) << 2) + ((row >> 4) & 3).
+ * Buffer size: (K / 128) * kstride * 4 bytes. */
+typedef struct fluxhip_fp8_mx {
+  /* consumer (exactly one of a_mx / c_mx is set per launch): A is e4m3 [M][lda] with block scales a_mx; sc->a_scale is not read */
+  const void* a_mx;
+  int32_t a_mx_row0[2];     /* first scale-buffer row of each group                                  */
+  int64_t a_mx_bstride;     /* scale-buffer rows between batches                                     */
+  int64_t a_mx_kstride;     /* dwords between K-steps of 128 elements (= rows of the scale buffer)   */
+  /* producer (epi GELU_TANH: every column; SPLIT_GELU: the columns >= n_split, stored at n - n_split + c8_coloff; the
+   * other columns go to C in bf16 as usual): e4m3 bytes c8[g] [M][ldc8] + block scales c_mx instead of bf16          */
+  void* c8[2];
+  int64_t c8_bstride;       /* bytes between batches of c8                                           */
+  int32_t ldc8, c8_coloff;
+  void* c_mx;
+  int32_t c_mx_row0[2];
+  int64_t c_mx_bstride, c_mx_kstride;
+} fluxhip_fp8_mx;
+/* fluxhip_gemm_fp8 with a block-scaled activation operand or a block-scaled output.  Every group's M must be a multiple
+ * of 64; runs unsplit on the ping-pong tiles (tile_cfg 49-52).  N % 32 == 0 for the producer form. */
+int fluxhip_gemm_fp8_mx(const fluxhip_gemm_desc* d, const fluxhip_fp8_scales* sc, const fluxhip_fp8_mx* mx, void* stream);
+/* x bf16 [rows][ld] (K columns) -> e4m3 out[rows][ld_out] at column col0 + block scales (tiling above; scale-buffer row =
+ * row0 + r).  K % 32 == 0, col0 % 32 == 0, row0 % 64 == 0, ld % 8 == 0, ld_out % 8 == 0. */
+int fluxhip_quantize_mx_fp8(const void* x, void* out, void* mx, int64_t rows, int K, int64_t ld, int64_t ld_out, int col0,
+                            int64_t row0, int64_t kstride, void* stream);
 
 /* ---- text encoders (flux/t5.py, flux/clip.py) ------------------------- */
 

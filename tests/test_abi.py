@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_loader_checks_abi_and_arch():
     from flux_generator_amd import _lib
     lib = _lib.load()
-    assert lib.fluxhip_abi_version() == 6 and lib.fluxhip_arch() == b"gfx950"
+    assert lib.fluxhip_abi_version() == 7 and lib.fluxhip_arch() == b"gfx950"
 
 
 def test_gemm_desc_layout_matches_header():
@@ -37,6 +37,8 @@ def test_gemm_desc_layout_matches_header():
     assert ctypes.sizeof(GemmDesc) == 288 and GemmDesc.C2.offset == 248 and GemmDesc.alpha.offset == 272
     assert GemmDesc.ld_add.offset == 280
     from flux_generator_amd._lib import GemmX3Desc      # fluxhip_gemm_x3_desc: 5 pointers, 7 int64, 10 int32, float, pad
+    from flux_generator_amd._lib import Fp8Mx
+    assert ctypes.sizeof(Fp8Mx) == 96 and Fp8Mx.c8.offset == 32 and Fp8Mx.ldc8.offset == 56 and Fp8Mx.c_mx.offset == 64
     assert ctypes.sizeof(GemmX3Desc) == 144 and GemmX3Desc.a_lo.offset == 40 and GemmX3Desc.M.offset == 96
     assert GemmX3Desc.alpha.offset == 136
 
