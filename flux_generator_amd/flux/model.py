@@ -72,6 +72,7 @@ class Flux:
         _lib.load()
         self._alloc_parameters()
         self._ws: "OrderedDict[Tuple[int, int, int], dict]" = OrderedDict()   # per-(B, S, L) workspaces + launch plans, LRU
+        self.fp8_mx = os.environ.get("FLUXHIP_FP8_MX", "1") != "0"   # fp8 mode: block-scaled hand-off GELU -> next Linear (0: per-token quantise passes)
         self.fp8 = False             # enable_fp8(): e4m3 weights + per-token e4m3 activations on the fp8 matrix cores
         self._w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._lora: Dict[str, Tuple[torch.Tensor, torch.Tensor, float]] = {}   # attach_lora(): layer -> (A^T pad, B^T pad, scale)
@@ -355,6 +356,12 @@ class Flux:
         if self.fp8:   # one (e4m3 rows, per-token scale) scratch pair shared by every GEMM input of the step
             ws["a8"] = buf(B * T, D + mlp, dtype=torch.uint8)
             ws["asc"] = buf(B * T, dtype=torch.float32)
+            # block-scaled ("MX") operands of mlp.layers.2 / linear2: written by the GELU epilogue of the GEMM before them
+            # (include/fluxhip.h, fluxhip_fp8_mx) - whole 64-row groups per stream and image
+            ws["mx"] = self.fp8_mx and S % 64 == 0 and L % 64 == 0
+            if ws["mx"]:
+                ws["a8m"] = buf(B * T, D + mlp, dtype=torch.uint8)
+                ws["amx"] = ops.mx_scale_buffer(B * T, D + mlp, dev)
         ws["plan"] = self._build_plan(ws)
         self._ws[key] = ws
         self._evict_workspaces()
@@ -437,6 +444,38 @@ class Flux:
             keep.extend([d, sc])
             call(lib.fluxhip_gemm_fp8, ctypes.byref(d), ctypes.byref(sc))
 
+        MX = bool(ws.get("mx"))
+
+        def gemm8mx(K, groups, wnames, N, ldc, epi, produce, ld8, coloff=0, **kw):
+            """Block-scaled forms of gemm8 (fluxhip_gemm_fp8_mx).  produce=True: per-token input from the shared scratch (K
+            wide), the GELU'd output leaves as e4m3 + block scales in `a8m` viewed as [B*T, ld8] from column `coloff`;
+            produce=False: the activation operand IS `a8m` ([B*T, ld8 = K]) with its block scales."""
+            gs, a_sc, w_sc, c8, rows = [], [], [], [], []
+            for g, wn in zip(groups, wnames):
+                wq, wscale = self._w8[wn]
+                row0 = g.pop("row0")
+                rows.append(row0)
+                if produce:
+                    g.update(A=ptr["a8"] + row0 * K, W=wq.data_ptr(), a_bstride=T * K)
+                    a_sc.append(ptr["asc"] + row0 * 4)
+                    c8.append(ptr["a8m"] + row0 * ld8)
+                else:
+                    g.update(A=ptr["a8m"] + row0 * ld8, W=wq.data_ptr(), a_bstride=T * ld8)
+                    a_sc.append(None)
+                gs.append(g)
+                w_sc.append(wscale.data_ptr())
+            if (N, K) in forced:
+                kw["tile_cfg"] = forced[(N, K)]
+            d = make_gemm_desc(gs, B, N, K, K if produce else ld8, ldc, epi, **kw)
+            sc = ops.make_fp8_scales(a_sc, w_sc, T)
+            if produce:
+                mxd = ops.make_fp8_mx(c8=c8, c8_bstride=T * ld8, ldc8=ld8, c8_coloff=coloff, c_mx=ptr["amx"], c_row0=rows,
+                                      c_bstride=T, c_kstride=B * T)
+            else:
+                mxd = ops.make_fp8_mx(a_mx=ptr["amx"], a_row0=rows, a_bstride=T, a_kstride=B * T)
+            keep.extend([d, sc, mxd])
+            call(lib.fluxhip_gemm_fp8_mx, ctypes.byref(d), ctypes.byref(sc), ctypes.byref(mxd))
+
         def small(x, wn, out, K, N, silu_in, accum):
             call(lib.fluxhip_small_linear_bf16, x, w(wn + ".weight"), wo(wn + ".bias"), out, B, N, K, silu_in, accum)
 
@@ -493,7 +532,8 @@ class Flux:
             sel = [(f"{prefix}.{st}_{wname}", r0) for st, r0, M in (("txt", 0, S), ("img", S, L)) if M]
             return dict(names=[n for n, _ in sel], rows=[r for _, r in sel])
 
-        def two_streams8(src, K, C, ldc, c_bs, wname, N, epi=EPI_BIAS, res=None, gate_off=None, i_off=0, t_off=0, prefix=""):
+        def two_streams8(src, K, C, ldc, c_bs, wname, N, epi=EPI_BIAS, res=None, gate_off=None, i_off=0, t_off=0, prefix="",
+                         mx=None):
             gs, wn = [], []
             for st, row0, M, moff in (("txt", 0, S, t_off), ("img", S, L, i_off)):
                 if M == 0:
@@ -503,7 +543,10 @@ class Flux:
                     g.update(res=res + row0 * ldc * e, gate=mp + (moff + gate_off) * e, gate_bstride=NM)
                 gs.append(g)
                 wn.append(f"{prefix}.{st}_{wname}")
-            gemm8(src, K, gs, wn, N, ldc, epi)
+            if mx is None:
+                gemm8(src, K, gs, wn, N, ldc, epi)
+            else:
+                gemm8mx(K, gs, wn, N, ldc, epi, mx == "produce", mlp)
 
         F8 = self.fp8
 
@@ -542,7 +585,11 @@ class Flux:
                 gemm(two_streams(ptr["attn"], D, T * D, ptr["x"], D, T * D, "attn.proj", res=ptr["x"], gate_off=2 * D,
                                  i_off=io, t_off=to, prefix=p), B, D, D, D, D, EPI_GATE_RES, **stream_names("attn.proj", p))
             src = ln_mod(mp + (to + 3 * D) * e, mp + (to + 4 * D) * e, mp + (io + 3 * D) * e, mp + (io + 4 * D) * e, S)
-            if F8:
+            if F8 and MX:     # GELU'd hidden state leaves mlp.layers.0 as e4m3 + block scales: no bf16 round trip, no quantise pass
+                two_streams8(None, D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", mlp, EPI_GELU_TANH, prefix=p, mx="produce")
+                two_streams8(None, mlp, ptr["x"], D, T * D, "mlp.layers.2", D, EPI_GATE_RES, res=ptr["x"],
+                             gate_off=5 * D, i_off=io, t_off=to, prefix=p, mx="consume")
+            elif F8:
                 two_streams8(src, D, ptr["hmlp"], mlp, T * mlp, "mlp.layers.0", mlp, EPI_GELU_TANH, prefix=p)
                 two_streams8(ptr["hmlp"], mlp, ptr["x"], D, T * D, "mlp.layers.2", D, EPI_GATE_RES, res=ptr["x"],
                              gate_off=5 * D, i_off=io, t_off=to, prefix=p)
@@ -556,7 +603,11 @@ class Flux:
             p = f"single_blocks.{i}"
             o = self.mod_off[f"{p}.modulation.lin"]
             src = ln_mod(None, None, mp + o * e, mp + (o + D) * e, 0)
-            if F8:
+            if F8 and MX:     # the GELU half of linear1 -> e4m3 + block scales at columns [D, D + mlp) of linear2's operand
+                gemm8mx(D, [dict(row0=0, bias=wo(f"{p}.linear1.bias"), C=ptr["qkv"], c_bstride=T * 3 * D, M=T)],
+                        [f"{p}.linear1"], 3 * D + mlp, 3 * D, EPI_SPLIT_GELU, True, D + mlp, coloff=D, n_split=3 * D,
+                        C2=ptr["cat"], ldc2=D + mlp, c2_bstride=T * (D + mlp), c2_coloff=D)
+            elif F8:
                 gemm8(src, D, [dict(row0=0, bias=wo(f"{p}.linear1.bias"), C=ptr["qkv"], c_bstride=T * 3 * D, M=T)],
                       [f"{p}.linear1"], 3 * D + mlp, 3 * D, EPI_SPLIT_GELU, n_split=3 * D, C2=ptr["cat"], ldc2=D + mlp,
                       c2_bstride=T * (D + mlp), c2_coloff=D)
@@ -568,6 +619,13 @@ class Flux:
             call(lib.fluxhip_qk_norm_rope_bf16, ptr["qkv"], 3 * D, B, T, 0, H, None, None,
                  w(f"{p}.norm.query_norm.weight"), w(f"{p}.norm.key_norm.weight"),
                  ptr["rope"], T * 128, ptr["Q"], ptr["K"], ptr["Vt"], Tpad, 1e-5)
+            if F8 and MX:     # attention output -> bf16 scratch -> block-scaled columns [0, D) of linear2's operand
+                call(lib.fluxhip_attention_d128_bf16, ptr["Q"], ptr["K"], ptr["Vt"], ptr["attn"], D, B, H, T, Tpad, 128 ** -0.5)
+                call(lib.fluxhip_quantize_mx_fp8, ptr["attn"], ptr["a8m"], ptr["amx"], B * T, D, D, D + mlp, 0, 0, B * T)
+                gemm8mx(D + mlp, [dict(row0=0, bias=wo(f"{p}.linear2.bias"), C=ptr["x"], res=ptr["x"],
+                                       gate=mp + (o + 2 * D) * e, gate_bstride=NM, c_bstride=T * D, M=T)],
+                        [f"{p}.linear2"], D, D, EPI_GATE_RES, False, D + mlp)
+                continue
             call(lib.fluxhip_attention_d128_bf16, ptr["Q"], ptr["K"], ptr["Vt"], ptr["cat"], D + mlp, B, H, T, Tpad,
                  128 ** -0.5)
             if F8:
@@ -637,6 +695,12 @@ class Flux:
                 flops = 2.0 * m_total * d.N * d.K
                 code = lib.fluxhip_gemm_fp8_tile_cfg(args[0])
                 label = f"fluxhip_gemm_fp8/cfg{code & 255}" + (f"s{code >> 8}" if (code >> 8) > 1 else "")
+            elif fn.__name__ == "fluxhip_gemm_fp8_mx":
+                d = args[0]._obj
+                flops = 2.0 * sum(d.g[i].M for i in range(d.ngroups)) * d.nbatch * d.N * d.K
+                label = "fluxhip_gemm_fp8_mx/" + ("A-block-scaled" if args[2]._obj.a_mx else "gelu->e4m3+scales")
+                if with_shape:
+                    label += f" N{d.N} K{d.K}"
             elif fn.__name__ == "fluxhip_attention_d128_bf16":
                 Bq, Hq, Tq = args[5], args[6], args[7]
                 flops = 4.0 * Bq * Hq * Tq * Tq * 128

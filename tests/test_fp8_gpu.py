@@ -118,6 +118,20 @@ def test_flux_forward_fp8(dev, B, S, hw):
     e, e16 = rel_l2(got, ref), rel_l2(got, bf16_out.float().cpu())
     print(f"fp8 tiny forward: rel-L2 vs oracle(dequantised weights) {e:.2e}; vs the bf16 HIP forward {e16:.2e}")
     assert e < 6e-2
+    # the block-scaled hand-off (GELU epilogue -> e4m3 + E8M0 block scales -> next Linear) is taken when every stream is whole
+    # 64-row groups; the per-token plan with its stand-alone quantise passes stays within the same budget of the oracle
+    ws = next(iter(model._ws.values()))
+    assert bool(ws["mx"]) == (S % 64 == 0 and (hw[0] // 2) * (hw[1] // 2) % 64 == 0)
+    if ws["mx"]:
+        fns = [f.__name__ for f, _ in ws["plan"] if hasattr(f, "__name__")]
+        assert fns.count("fluxhip_gemm_fp8_mx") == 2 * 2 + 2 * 3 and fns.count("fluxhip_quantize_rows_fp8") == 2     # left: attention out -> attn.proj
+        model.fp8_mx = False
+        model.enable_fp8()
+        per_token = model(*args)
+        model.fp8_mx = True
+        e_pt = rel_l2(per_token, ref)
+        print(f"   per-token plan vs oracle {e_pt:.2e}; block-scaled vs per-token plan {rel_l2(got, per_token.float().cpu()):.2e}")
+        assert e_pt < 6e-2 and e < 1.25 * e_pt + 5e-3
     model.enable_fp8(False)
     assert torch.equal(model(*args), bf16_out)                    # switching back restores the bf16 plan exactly
 
