@@ -39,6 +39,11 @@ struct AttnParams {
   float scale;              // MODE 1: logits = scale * q.k + bias
   const bf16_t* bias;       // MODE 1: additive bias [H][Tq][Tk] (T5 relative position bias)
   int force_slow;           // attn128_w64_kernel: take the online-rescale fallback (tests)
+  // MXO kernels: the output leaves as e4m3 bytes O8 [B * Tq][ldo] + E8M0 block scales in the tiled layout of the block-scaled
+  // fp8 GEMM (include/fluxhip.h, fluxhip_fp8_mx): scale-buffer row = b * Tq + q, 32-column block = h * HD / 32 + db
+  uint8_t* O8;
+  uint8_t* mx;
+  long long mx_kstride;
 };
 
 // MODE 0: plain; MODE 1: additive per-head bias (flux/t5.py:70-116,153-155: scale 1.0, bias passed as
@@ -60,7 +65,7 @@ DEVINL f32x16 mfma32(const bf16x8 a, const bf16x8 b, const f32x16 c) {
 
 // F16: the 16-bit storage type is IEEE float16 (stable_diffusion/ with float16=True) instead of bfloat16: the S and PV products
 // run on v_mfma_f32_32x32x16_f16, P is rounded to float16 (<= 256 under the lazy rescale, far inside its range)
-template <int HD, int NW, int MODE, int KS = 1, int VP = 0, bool F16 = false>
+template <int HD, int NW, int MODE, int KS = 1, int VP = 0, bool F16 = false, bool MXO = false>
 __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(const AttnParams p) {
   constexpr int RB = HD * 2;                  // bytes per K row
   constexpr int CPR = RB / 16;                // 16-B chunks per K row
@@ -362,6 +367,38 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
   const float l_tot = pair32_sum(l_run);
   const float inv = 1.f / l_tot;
   const int q = q0 + ql;
+  if constexpr (MXO) {
+    // e4m3 + one E8M0 scale per 32 output columns: block db of query q is the 16 values of this lane and the 16 of lane ^ 32
+    // (the arithmetic of the FLAG_MXC GEMM epilogue: 2^e = smallest power of two with max|v| / 2^e <= 448)
+    const long long grow = (long long)b * Tq + min(q, Tq - 1);
+    uint8_t* orow8 = p.O8 + grow * p.ldo + h * HD;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      float v[16];
+      float am = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { v[r] = oT[db][r] * inv; am = fmaxf(am, fabsf(v[r])); }
+      am = fmaxf(am, __shfl_xor(am, 32, 64));
+      const uint32_t ab = __builtin_bit_cast(uint32_t, am);
+      int e8 = (int)(ab >> 23) - 8 + (int)((ab & 0x7fffffu) > 0x600000u);
+      e8 = min(max(e8, 1), 253);
+      const float mul = __builtin_bit_cast(float, (uint32_t)(254 - e8) << 23);
+      if (q < Tq) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          int w = 0;
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(v[rg * 4 + 0] * mul, v[rg * 4 + 1] * mul, w, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(v[rg * 4 + 2] * mul, v[rg * 4 + 3] * mul, w, true);
+          *(uint32_t*)(orow8 + db * 32 + 8 * rg + 4 * hi) = (uint32_t)w;
+        }
+        if (hi == 0) {
+          const int kb = h * (HD / 32) + db;
+          p.mx[((((long long)(kb >> 2) * p.mx_kstride + (grow >> 6) * 64 + (kb & 3) * 16 + (grow & 15)) << 2) + ((grow >> 4) & 3))] = (uint8_t)e8;
+        }
+      }
+    }
+    return;
+  }
   if (q < Tq) {
     bf16_t* orow = p.O + ((long long)b * Tq + q) * p.ldo + h * HD;
 #pragma unroll
@@ -814,11 +851,11 @@ int launch_attn128_w64(AttnParams p, int B, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 
-template <int HD, int MODE, int KS = 1, int VP = 0, bool F16 = false>
+template <int HD, int MODE, int KS = 1, int VP = 0, bool F16 = false, bool MXO = false>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
   constexpr int NW = 4;
   constexpr int lds = 2 * KS * (KV * HD * 2 + HD * KV * 2);
-  auto fn = attn_kernel<HD, NW, MODE, KS, VP, F16>;
+  auto fn = attn_kernel<HD, NW, MODE, KS, VP, F16, MXO>;
   static bool done = false;            // one flag per template instantiation
   if (!done) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -860,6 +897,27 @@ extern "C" int fluxhip_attention_d128_bf16(const void* Q, const void* K, const v
   //  +-4 % of attn_kernel on every Flux shape — 257 vs 263 us at T = 4352, 273 vs 283 at T = 4608, 945 vs 921 at B = 4 —
   //  both are bound by instruction issue, ~13 non-MFMA instructions per MFMA in its S phases)
   return launch_attn<128, 0, 1, 1>(p, B, (hipStream_t)stream);
+}
+
+// fluxhip_attention_d128_bf16 with the fp8 quantisation of the NEXT Linear's operand fused into the finalize step: out8 is
+// e4m3 [B * T][ld8] (head h at columns [128 h, 128 h + 128)), mx the tiled E8M0 block scales (row = b * T + t).
+extern "C" int fluxhip_attention_d128_mx(const void* Q, const void* K, const void* Vt, void* out8, int ld8, void* mx,
+                                         int64_t mx_kstride, int B, int H, int T, int Tpad, float scale, void* stream) {
+  if (!Q || !K || !Vt || !out8 || !mx || B < 1 || H < 1 || T < 1 || Tpad % 64 || Tpad < T || ld8 % 4 || ld8 < H * 128 ||
+      mx_kstride % 64 || mx_kstride < (int64_t)B * T || ((uintptr_t)out8 & 3))
+    return FLUXHIP_EINVAL;
+  AttnParams p{};
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt;
+  p.O8 = (uint8_t*)out8; p.mx = (uint8_t*)mx; p.mx_kstride = mx_kstride;
+  p.q_rs = p.k_rs = 128;
+  p.q_hs = p.k_hs = (long long)T * 128;
+  p.q_bs = p.k_bs = (long long)H * T * 128;
+  p.ldo = ld8; p.H = H; p.Tq = T; p.Tk = T; p.Tkpad = Tpad;
+  p.vt_bs = (long long)H * 128 * Tpad;
+  p.nqb = (T + 127) / 128;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  if ((long long)B * H * p.nqb < 384 && T > 2 * KV) return launch_attn<128, 0, 2, 1, false, true>(p, B, (hipStream_t)stream);
+  return launch_attn<128, 0, 1, 1, false, true>(p, B, (hipStream_t)stream);
 }
 
 extern "C" int fluxhip_attention_set_variant(int v) {

@@ -546,7 +546,7 @@ class Flux:
             if mx is None:
                 gemm8(src, K, gs, wn, N, ldc, epi)
             else:
-                gemm8mx(K, gs, wn, N, ldc, epi, mx == "produce", mlp)
+                gemm8mx(K, gs, wn, N, ldc, epi, mx == "produce", mlp if mx == "produce" else K)
 
         F8 = self.fp8
 
@@ -576,12 +576,18 @@ class Flux:
                  wo(f"{p}.txt_attn.norm.query_norm.weight"), wo(f"{p}.txt_attn.norm.key_norm.weight"),
                  w(f"{p}.img_attn.norm.query_norm.weight"), w(f"{p}.img_attn.norm.key_norm.weight"),
                  ptr["rope"], T * 128, ptr["Q"], ptr["K"], ptr["Vt"], Tpad, 1e-5)
-            call(lib.fluxhip_attention_d128_bf16, ptr["Q"], ptr["K"], ptr["Vt"], ptr["attn"], D, B, H, T, Tpad,
-                 128 ** -0.5)
-            if F8:
+            if F8 and MX:     # attention's finalize step quantises its own output: e4m3 + block scales, attn.proj's operand
+                call(lib.fluxhip_attention_d128_mx, ptr["Q"], ptr["K"], ptr["Vt"], ptr["a8m"], D, ptr["amx"], B * T, B, H, T, Tpad,
+                     128 ** -0.5)
+                two_streams8(None, D, ptr["x"], D, T * D, "attn.proj", D, EPI_GATE_RES, res=ptr["x"], gate_off=2 * D,
+                             i_off=io, t_off=to, prefix=p, mx="consume")
+            else:
+                call(lib.fluxhip_attention_d128_bf16, ptr["Q"], ptr["K"], ptr["Vt"], ptr["attn"], D, B, H, T, Tpad,
+                     128 ** -0.5)
+            if F8 and not MX:
                 two_streams8(ptr["attn"], D, ptr["x"], D, T * D, "attn.proj", D, EPI_GATE_RES, res=ptr["x"], gate_off=2 * D,
                              i_off=io, t_off=to, prefix=p)
-            else:
+            elif not F8:
                 gemm(two_streams(ptr["attn"], D, T * D, ptr["x"], D, T * D, "attn.proj", res=ptr["x"], gate_off=2 * D,
                                  i_off=io, t_off=to, prefix=p), B, D, D, D, D, EPI_GATE_RES, **stream_names("attn.proj", p))
             src = ln_mod(mp + (to + 3 * D) * e, mp + (to + 4 * D) * e, mp + (io + 3 * D) * e, mp + (io + 4 * D) * e, S)
@@ -619,9 +625,9 @@ class Flux:
             call(lib.fluxhip_qk_norm_rope_bf16, ptr["qkv"], 3 * D, B, T, 0, H, None, None,
                  w(f"{p}.norm.query_norm.weight"), w(f"{p}.norm.key_norm.weight"),
                  ptr["rope"], T * 128, ptr["Q"], ptr["K"], ptr["Vt"], Tpad, 1e-5)
-            if F8 and MX:     # attention output -> bf16 scratch -> block-scaled columns [0, D) of linear2's operand
-                call(lib.fluxhip_attention_d128_bf16, ptr["Q"], ptr["K"], ptr["Vt"], ptr["attn"], D, B, H, T, Tpad, 128 ** -0.5)
-                call(lib.fluxhip_quantize_mx_fp8, ptr["attn"], ptr["a8m"], ptr["amx"], B * T, D, D, D + mlp, 0, 0, B * T)
+            if F8 and MX:     # attention output -> block-scaled columns [0, D) of linear2's operand (the GELU half is there already)
+                call(lib.fluxhip_attention_d128_mx, ptr["Q"], ptr["K"], ptr["Vt"], ptr["a8m"], D + mlp, ptr["amx"], B * T, B, H, T,
+                     Tpad, 128 ** -0.5)
                 gemm8mx(D + mlp, [dict(row0=0, bias=wo(f"{p}.linear2.bias"), C=ptr["x"], res=ptr["x"],
                                        gate=mp + (o + 2 * D) * e, gate_bstride=NM, c_bstride=T * D, M=T)],
                         [f"{p}.linear2"], D, D, EPI_GATE_RES, False, D + mlp)

@@ -406,6 +406,10 @@ int fluxhip_gemm_fp8_mx(const fluxhip_gemm_desc* d, const fluxhip_fp8_scales* sc
  * row0 + r).  K % 32 == 0, col0 % 32 == 0, row0 % 64 == 0, ld % 8 == 0, ld_out % 8 == 0. */
 int fluxhip_quantize_mx_fp8(const void* x, void* out, void* mx, int64_t rows, int K, int64_t ld, int64_t ld_out, int col0,
                             int64_t row0, int64_t kstride, void* stream);
+/* fluxhip_attention_d128_bf16 whose output leaves as the block-scaled operand of the next Linear: out8 e4m3 [B*T][ld8] (head h
+ * at columns [128 h, 128 h + 128)), mx = tiled block scales with scale-buffer row b * T + t (mx_kstride >= B * T). */
+int fluxhip_attention_d128_mx(const void* Q, const void* K, const void* Vt, void* out8, int ld8, void* mx, int64_t mx_kstride,
+                              int B, int H, int T, int Tpad, float scale, void* stream);
 
 /* ---- text encoders (flux/t5.py, flux/clip.py) ------------------------- */
 

@@ -124,7 +124,8 @@ def test_flux_forward_fp8(dev, B, S, hw):
     assert bool(ws["mx"]) == (S % 64 == 0 and (hw[0] // 2) * (hw[1] // 2) % 64 == 0)
     if ws["mx"]:
         fns = [f.__name__ for f, _ in ws["plan"] if hasattr(f, "__name__")]
-        assert fns.count("fluxhip_gemm_fp8_mx") == 2 * 2 + 2 * 3 and fns.count("fluxhip_quantize_rows_fp8") == 2     # left: attention out -> attn.proj
+        assert fns.count("fluxhip_gemm_fp8_mx") == 3 * 2 + 2 * 3 and fns.count("fluxhip_attention_d128_mx") == 2 + 3
+        assert not any("quantize" in f for f in fns)              # no stand-alone quantise pass left in the step
         model.fp8_mx = False
         model.enable_fp8()
         per_token = model(*args)

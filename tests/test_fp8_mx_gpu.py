@@ -152,3 +152,43 @@ def test_gemm_split_gelu_mxc(dev):
     ge = mx_untile(mx, M, D + mlp)[:, D // 32:]
     assert rel_l2(mx_dequantize(cat8[:, D:].cpu(), ge), act) <= 5e-2
     assert int(cat8[:, :D].sum()) == 0
+
+
+@pytest.mark.parametrize("B,H,T", [(1, 2, 192), (2, 3, 320), (1, 24, 1280)])
+def test_attention_mx_output(dev, B, H, T):
+    """fluxhip_attention_d128_mx = fluxhip_attention_d128_bf16 followed by the block quantiser, without the bf16 rounding in
+    between: scale bytes equal the oracle's quantisation of the bf16 output except where that rounding moves a block maximum
+    across a power of two; de-quantised result within the e4m3 budget of the bf16 kernel's output."""
+    from flux_generator_amd import _lib, ops
+    torch.manual_seed(B * 100 + T)
+    lib = _lib.load()
+    Tpad = (T + 63) // 64 * 64
+    Q = torch.randn(B, H, T, 128, device=dev).to(BF16)
+    K = torch.randn(B, H, T, 128, device=dev).to(BF16)
+    V = torch.randn(B, H, T, 128, device=dev).to(BF16)
+    Vt = torch.zeros(B, H, 128, Tpad, dtype=BF16, device=dev)
+    Vt[..., :T] = V.transpose(2, 3)
+    s = torch.cuda.current_stream().cuda_stream
+    D = H * 128
+    # the kernels read V^T in the key-permuted layout fluxhip_qk_norm_rope_bf16 writes; both variants read the SAME buffer here,
+    # so the comparison holds whatever the permutation is
+    Vt = Vt.reshape(B, H, 128, Tpad).contiguous()
+    ref = torch.empty(B, T, D, dtype=BF16, device=dev)
+    assert lib.fluxhip_attention_d128_bf16(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), ref.data_ptr(), D, B, H, T, Tpad, 128 ** -0.5, s) == 0
+    rows = (B * T + 63) // 64 * 64
+    ld8 = D + 128                                            # a wider operand buffer, like linear2's
+    out8 = torch.zeros(B * T, ld8, dtype=torch.uint8, device=dev)
+    mx = ops.mx_scale_buffer(rows, (ld8 + 127) // 128 * 128, dev)
+    assert lib.fluxhip_attention_d128_mx(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out8.data_ptr(), ld8, mx.data_ptr(), rows, B, H, T,
+                                         Tpad, 128 ** -0.5, s) == 0
+    torch.cuda.synchronize()
+    ge = mx_untile(mx, B * T, D, 0, rows)
+    got = mx_dequantize(out8[:, :D].cpu(), ge)
+    want = ref.reshape(B * T, D).float().cpu()
+    wq, we = mx_quantize(want)
+    same = float((ge == we).float().mean())
+    e = rel_l2(got, want)
+    print(f"attention -> e4m3 + block scales B{B} H{H} T{T}: scale bytes equal {same:.4f}, de-quantised vs bf16 output rel-L2 {e:.2e} "
+          f"(oracle quantiser of the bf16 output: {rel_l2(mx_dequantize(wq, we), want):.2e})")
+    assert same >= 0.99 and int((ge.int() - we.int()).abs().max()) <= 1 and e <= 5e-2
+    assert int(out8[:, D:].sum()) == 0
