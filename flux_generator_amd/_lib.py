@@ -114,6 +114,7 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "fluxhip_gemm_fp8": (c_int, [C.POINTER(GemmDesc), C.POINTER(Fp8Scales), c_void_p]),
     "fluxhip_gemm_fp8_tile_cfg": (c_int, [C.POINTER(GemmDesc)]),
+    "fluxhip_debug_checksum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "fluxhip_gemm_fp8_mx": (c_int, [C.POINTER(GemmDesc), C.POINTER(Fp8Scales), C.POINTER(Fp8Mx), c_void_p]),
     "fluxhip_attention_d128_mx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int,
                                           c_int, c_float, c_void_p]),

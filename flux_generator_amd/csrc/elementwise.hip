@@ -909,6 +909,24 @@ extern "C" int fluxhip_quantize_mx_fp8(const void* x, void* out, void* mx, int64
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 
+// ---- diagnostic: 64-bit sum of the 32-bit words of a buffer into out[0] (tools/rare_divergence_hunt.py: per-launch checksums
+// without leaving the library's own kernels) ------------------------------------------------------------------------------
+__global__ void debug_zero_kernel(unsigned long long* out) { *out = 0ull; }
+__global__ __launch_bounds__(256) void debug_checksum_kernel(const uint32_t* __restrict__ x, long long n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += x[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+extern "C" int fluxhip_debug_checksum(const void* x, int64_t nwords, void* out, void* stream) {
+  if (!x || !out || nwords < 1) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL(debug_zero_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out);
+  hipLaunchKernelGGL(debug_checksum_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)x, (long long)nwords,
+                     (unsigned long long*)out);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
 // ---- fp8 row quantiser entry points ---------------------------------------------------------------
 extern "C" int fluxhip_quantize_rows_fp8(const void* x, void* out, void* scale, int64_t rows, int K, int64_t ld,
                                          void* stream) {

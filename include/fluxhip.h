@@ -372,6 +372,9 @@ typedef struct fluxhip_fp8_scales {
 int fluxhip_gemm_fp8(const fluxhip_gemm_desc* d, const fluxhip_fp8_scales* sc, void* stream);
 int fluxhip_gemm_fp8_tile_cfg(const fluxhip_gemm_desc* d);
 
+/* diagnostic (tools/rare_divergence_hunt.py): out[0] (uint64) = sum of the nwords 32-bit words at x */
+int fluxhip_debug_checksum(const void* x, int64_t nwords, void* out, void* stream);
+
 /* ---- block-scaled ("MX") fp8: quantisation fused into the producing kernel ---------------------------------------
  * A per-token scale needs the whole row before the first byte can be written, which forces a stand-alone quantise pass
  * between a producer (GELU epilogue, attention) and the next Linear.  With one power-of-two scale per 32 consecutive
