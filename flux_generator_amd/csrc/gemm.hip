@@ -282,9 +282,10 @@ const Cand kX3Cands[] = {
 //  layers to worse tiles - the other rows of this table are as mis-scaled - so until the whole table is refitted in the dense
 //  table's form only the one ranking that was wrong is corrected.)
 const Cand kX3ConvCands[] = {
-    {49, 1, 1.850f, 6.0f}, {10, 1, 1.110f, 4.8f}, {55, 1, 1.050f, 8.2f}, {7, 2, 1.155f, 4.0f},
+    {49, 1, 1.850f, 6.0f}, {52, 1, 1.100f, 4.8f}, {10, 1, 1.110f, 4.8f}, {55, 1, 1.050f, 8.2f}, {7, 2, 1.155f, 4.0f},
     {8, 2, 0.847f, 0.30f}, {9, 2, 0.672f, 2.90f}, {4, 2, 0.483f, 1.15f},
-};
+};   // (52 = the 256x128 tile on the ping-pong schedule, round 4: takes exactly the layers the plain-ring 256x128 tile had - the
+     //  128-output-channel convs at 512^2: 518 vs 544 us and 286 vs 290 us, tools/conv_tune_x3.py - and nothing else)
 
 // fp8 kernels: the ping-pong tiles (time per K-step as measured for bf16: a K-step is the same 128 bytes per row) and
 // the simple-ring tiles for small shapes.
