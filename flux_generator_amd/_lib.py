@@ -115,6 +115,7 @@ SIGNATURES = {
     "fluxhip_gemm_fp8": (c_int, [C.POINTER(GemmDesc), C.POINTER(Fp8Scales), c_void_p]),
     "fluxhip_gemm_fp8_tile_cfg": (c_int, [C.POINTER(GemmDesc)]),
     "fluxhip_debug_checksum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "fluxhip_debug_checksum_lds": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "fluxhip_gemm_fp8_mx": (c_int, [C.POINTER(GemmDesc), C.POINTER(Fp8Scales), C.POINTER(Fp8Mx), c_void_p]),
     "fluxhip_attention_d128_mx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int,
                                           c_int, c_float, c_void_p]),

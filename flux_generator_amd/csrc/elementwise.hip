@@ -919,6 +919,35 @@ __global__ __launch_bounds__(256) void debug_checksum_kernel(const uint32_t* __r
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
+// the same reduction staged through `LDS_WORDS` words of LDS per workgroup (tools/cotenant_fault_bisect.py: does LDS use alone make a
+// kernel take part in the shared-GPU fault of DESIGN.md 3.8b?)
+template <int LDS_WORDS>
+__global__ __launch_bounds__(256) void debug_checksum_lds_kernel(const uint32_t* __restrict__ x, long long n, unsigned long long* out) {
+  __shared__ uint32_t stage[LDS_WORDS];
+  unsigned long long acc = 0;
+  for (long long i0 = (long long)blockIdx.x * 256; i0 < n; i0 += (long long)gridDim.x * 256) {
+    const long long i = i0 + threadIdx.x;
+    stage[(threadIdx.x * 17) % LDS_WORDS] = i < n ? x[i] : 0u;       // a conflict-free permutation of the first 256 words' slots
+    __syncthreads();
+    acc += stage[((255 - threadIdx.x) * 17) % LDS_WORDS];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+extern "C" int fluxhip_debug_checksum_lds(const void* x, int64_t nwords, void* out, int lds_kib, void* stream) {
+  if (!x || !out || nwords < 1 || (lds_kib != 16 && lds_kib != 60)) return FLUXHIP_EINVAL;
+  hipLaunchKernelGGL(debug_zero_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out);
+  if (lds_kib == 16)
+    hipLaunchKernelGGL(debug_checksum_lds_kernel<4096>, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)x,
+                       (long long)nwords, (unsigned long long*)out);
+  else
+    hipLaunchKernelGGL(debug_checksum_lds_kernel<15360>, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)x,
+                       (long long)nwords, (unsigned long long*)out);
+  return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
+}
+
 extern "C" int fluxhip_debug_checksum(const void* x, int64_t nwords, void* out, void* stream) {
   if (!x || !out || nwords < 1) return FLUXHIP_EINVAL;
   hipLaunchKernelGGL(debug_zero_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out);

@@ -374,6 +374,8 @@ int fluxhip_gemm_fp8_tile_cfg(const fluxhip_gemm_desc* d);
 
 /* diagnostic (tools/rare_divergence_hunt.py): out[0] (uint64) = sum of the nwords 32-bit words at x */
 int fluxhip_debug_checksum(const void* x, int64_t nwords, void* out, void* stream);
+/* ... staged through lds_kib (16 or 60) KiB of LDS per workgroup (diagnostic: DESIGN.md 3.8b) */
+int fluxhip_debug_checksum_lds(const void* x, int64_t nwords, void* out, int lds_kib, void* stream);
 
 /* ---- block-scaled ("MX") fp8: quantisation fused into the producing kernel ---------------------------------------
  * A per-token scale needs the whole row before the first byte can be written, which forces a stand-alone quantise pass
