@@ -418,6 +418,23 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
   if (x3)   // three passes over K
     return conv ? pick_from(kX3ConvCands, group_m, ngroups, nbatch, N, 3 * K)
                 : pick_from(kX3Cands, group_m, ngroups, nbatch, N, 3 * K);
+  if (!conv) {
+    // Skinny launches (the text towers: M = 256 rows against 34-84 MB of weights) are HBM streaming, not MFMA work, and the cost
+    // model - fitted at M >= 1280 - under-prices a split for them: at M = 256 the 128 x 128 tile covers N = 4096 / 8192 with 64 /
+    // 128 blocks, and splitting K until ~256 blocks are in flight is what raises the weight stream (tools/gemm_tune.py, cold
+    // weights: q/k 423 -> 511 TFLOP/s with S = 2, out-proj 212 -> 281 and wo 369 -> 426 with S = 3).  M = 512 is left to the model.
+    long long m_total = 0;
+    for (int g = 0; g < ngroups; ++g) m_total += (long long)group_m[g] * nbatch;
+    long long tiles = 0;
+    for (int g = 0; g < ngroups; ++g) tiles += (long long)((group_m[g] + 127) / 128) * nbatch;
+    tiles *= (N + 127) / 128;
+    if (m_total <= 256 && K >= 2048 && N >= 1024 && tiles <= 128) {
+      int S = (int)(256 / tiles);
+      S = S > 3 ? 3 : S;
+      while (S > 1 && (K / 64) / S < 16) --S;
+      if (S > 1 && kSkFlagBytes + tiles * 128 * 128 * 4LL <= g_ws_bytes) return 47 | (S << 8);
+    }
+  }
   return conv ? pick_from(kConvCands, group_m, ngroups, nbatch, N, K, kConvForm)
               : rs ? pick_from<sizeof(kCands) / sizeof(kCands[0]), true>(kCands, group_m, ngroups, nbatch, N, K, kDenseForm)
                    : pick_from(kCands, group_m, ngroups, nbatch, N, K, kDenseForm);
