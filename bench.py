@@ -510,7 +510,7 @@ def main() -> None:
             "per_rank": rank_diag,
             "collectives": (("gloo; ALL RANKS SHARE ONE GPU (BENCH_SHARE_GPU diagnostic): not a scaling measurement" if share_gpu else
                              f"RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())} (torch.distributed nccl backend)") if use_dist else None),
-            "dtype": "fp8 e4m3 (block Linears: weights per-channel, activations per-token; residual stream / attention / VAE as in bf16 mode)" if args.fp8 else "bf16",
+            "dtype": "fp8 e4m3 (block Linears: weights per-channel; activations per-token out of LayerNorm, block-scaled (E8M0 per 32) out of attention / GELU; residual stream / attention / VAE as in bf16 mode)" if args.fp8 else "bf16",
             "data": "synthetic",
             "config": {"workload": f"{args.model.replace('flux-', 'Flux-')} {args.image_size}x{args.image_size} {args.denoise_steps}-step, "
                                    f"batch {B}/GPU, random-init weights, synthetic x_T/txt/vec resident in HBM; "
