@@ -32,7 +32,7 @@ def build_parser():
     p.add_argument("--n-rows", type=int, default=1)
     p.add_argument("--decoding-batch-size", type=int, default=1)
     p.add_argument("--quantize", "-q", action="store_true",
-                   help="fp8 (e4m3) weights + per-token fp8 activations on the fp8 matrix cores for the Linears of the flow "
+                   help="fp8 (e4m3) weights + fp8 activations (per-token scales out of LayerNorm, block scales out of attention / GELU) on the fp8 matrix cores for the Linears of the flow "
                         "transformer's blocks (99.6%% of its FLOPs), of the T5 encoder and of CLIP (the layers the reference's "
                         "in_dim %% 512 predicate selects)")
     p.add_argument("--preload-models", action="store_true")
@@ -84,7 +84,7 @@ def main(argv=None):
               file=sys.stderr)
     if args.quantize:
         # the reference's nn.quantize (txt2image.py:79-82) re-designed for CDNA4: e4m3 weights (per output channel) and
-        # per-token e4m3 activations of the transformer blocks' Linears on the fp8 matrix cores
+        # e4m3 activations (per token / block-scaled) of the transformer blocks' Linears on the fp8 matrix cores
         flux.flow.enable_fp8()
         flux.quantize_text()
         print("--quantize: fp8 e4m3 Linears in the flow transformer's blocks, the T5 encoder (all but the value projection) and "
