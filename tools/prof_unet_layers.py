@@ -58,11 +58,11 @@ def mk(groups, nbatch, N, K, lda, ldc, *a, **k):
     return _mk(groups, nbatch, N, K, lda, ldc, *a, **k)
 unet_mod.make_gemm_desc = mk
 _g = ops.gemm
-def gemm(desc):
+def gemm(desc, *a, **k):
     if not _last.pop("fresh", False):
-        return _g(desc)
+        return _g(desc, *a, **k)
     e0, e1 = ev(), ev()
-    e0.record(); _g(desc); e1.record()
+    e0.record(); _g(desc, *a, **k); e1.record()
     M, nb, N, K = _last["d"]
     log.append(("gemm(V^T)", f"M{M} N{N} K{K} nb{nb}", 2.0 * M * N * K * nb, e0, e1))
 ops.gemm = gemm
