@@ -307,8 +307,10 @@ const Cand kF8Cands[] = {          // (t_step per 128-byte K-step, t_fixed) fitt
 };
 
 // block-scaled fp8 (FLAG_MXA / FLAG_MXC): the ping-pong tiles that carry those kernels, unsplit (rows of kF8Cands)
-const Cand kF8MxaCands[] = {{49, 1, 1.398f, 22.8f}, {50, 1, 1.460f, 13.2f}, {51, 1, 1.360f, 11.2f}, {52, 1, 1.137f, 11.1f}};
-const Cand kF8MxcCands[] = {{49, 1, 1.398f, 22.8f}, {51, 1, 1.360f, 11.2f}, {52, 1, 1.137f, 11.1f}};
+const Cand kF8MxaCands[] = {{49, 1, 1.398f, 22.8f}, {50, 1, 1.460f, 13.2f}, {51, 1, 1.360f, 11.2f}, {52, 1, 1.137f, 11.1f},
+                             {55, 1, 0.927f, 10.1f}, {53, 1, 0.815f, 2.8f}};
+const Cand kF8MxcCands[] = {{49, 1, 1.398f, 22.8f}, {51, 1, 1.360f, 11.2f}, {52, 1, 1.137f, 11.1f},
+                             {55, 1, 0.927f, 10.1f}, {53, 1, 0.815f, 2.8f}};
 
 // Split-K workspace (fluxhip_set_workspace): [kSkMaxTiles] int32 hand-off counters (reduce-scatter mode: arrival counters
 // in the first half, departure counters in the second), then fp32 partial tiles.

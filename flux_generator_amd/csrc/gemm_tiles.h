@@ -34,8 +34,10 @@
 
 // block-scaled fp8 (gemm_mx.hip): FLAG_MXA = activation operand with E8M0 block scales (the tiles the N = 3072 projections
 // run on), FLAG_MXC = e4m3 + block-scale output (32-column blocks must sit inside a wave's sub-tile: BN / WN % 32 == 0)
-#define FLUXHIP_TILES_MXA(X) X(256, 256, 4, 2, 2, 6) X(256, 224, 4, 2, 2, 6) X(256, 192, 4, 2, 2, 6) X(256, 128, 4, 2, 2, 6)
-#define FLUXHIP_TILES_MXC(X) X(256, 256, 4, 2, 2, 6) X(256, 192, 4, 2, 2, 6) X(256, 128, 4, 2, 2, 6)
+#define FLUXHIP_TILES_MXA(X) X(256, 256, 4, 2, 2, 6) X(256, 224, 4, 2, 2, 6) X(256, 192, 4, 2, 2, 6) X(256, 128, 4, 2, 2, 6) \
+  X(128, 256, 2, 4, 2, 6) X(128, 128, 2, 4, 2, 6)
+#define FLUXHIP_TILES_MXC(X) X(256, 256, 4, 2, 2, 6) X(256, 192, 4, 2, 2, 6) X(256, 128, 4, 2, 2, 6) \
+  X(128, 256, 2, 4, 2, 6) X(128, 128, 2, 4, 2, 6)
 
 // float16-storage (FLAG_F16) kernels: the tiles the dense / conv pickers can return (kCands, kConvCands in gemm.hip), the
 // plain-ring 256 x 256 conv tile of the fused-upsample loader, and the two tiles that carry the GEGLU pair epilogue.

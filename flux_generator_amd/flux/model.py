@@ -73,7 +73,7 @@ class Flux:
         self._alloc_parameters()
         self._ws: "OrderedDict[Tuple[int, int, int], dict]" = OrderedDict()   # per-(B, S, L) workspaces + launch plans, LRU
         self.fp8_mx = os.environ.get("FLUXHIP_FP8_MX", "1") != "0"   # fp8 mode: block-scaled hand-off GELU -> next Linear (0: per-token quantise passes)
-        self.fp8_mx_min_rows = 2048
+        self.fp8_mx_min_rows = int(os.environ.get("FLUXHIP_FP8_MX_MIN_ROWS", "0"))
         self.fp8 = False             # enable_fp8(): e4m3 weights + per-token e4m3 activations on the fp8 matrix cores
         self._w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._lora: Dict[str, Tuple[torch.Tensor, torch.Tensor, float]] = {}   # attach_lora(): layer -> (A^T pad, B^T pad, scale)
@@ -359,9 +359,9 @@ class Flux:
             ws["asc"] = buf(B * T, dtype=torch.float32)
             # block-scaled ("MX") operands of mlp.layers.2 / linear2: written by the GELU epilogue of the GEMM before them
             # (include/fluxhip.h, fluxhip_fp8_mx) - whole 64-row groups per stream and image
-            # ... and enough rows for the unsplit 256-row tiles those kernels exist for: at B*T = 1280 (one 512^2 image) the
-            # per-token plan, which may split K or take 128-row tiles, is 9 % faster (13.2 vs 14.5 ms per step); from 2560 rows on
-            # the block-scaled plan wins (22.6 vs 23.2 ms at B = 2; 45.5 vs 47.6 ms at 1024^2)
+            # (fp8_mx_min_rows / FLUXHIP_FP8_MX_MIN_ROWS: a row threshold for A/B runs.  With 256-row tiles only, one 512^2 image
+            #  - B*T = 1280 - was 9 % slower block-scaled, 14.5 vs 13.2 ms per step; with the 128-row ping-pong tiles it is level,
+            #  13.46 vs 13.51, and ahead from two images on: 22.6 vs 23.5 ms)
             ws["mx"] = self.fp8_mx and S % 64 == 0 and L % 64 == 0 and B * T >= self.fp8_mx_min_rows
             if ws["mx"]:
                 ws["a8m"] = buf(B * T, D + mlp, dtype=torch.uint8)

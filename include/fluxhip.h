@@ -405,7 +405,7 @@ typedef struct fluxhip_fp8_mx {
   int64_t c_mx_bstride, c_mx_kstride;
 } fluxhip_fp8_mx;
 /* fluxhip_gemm_fp8 with a block-scaled activation operand or a block-scaled output.  Every group's M must be a multiple
- * of 64; runs unsplit on the ping-pong tiles (tile_cfg 49-52).  N % 32 == 0 for the producer form. */
+ * of 64; runs unsplit on the ping-pong tiles (tile_cfg 49-53, 55).  N % 32 == 0 for the producer form. */
 int fluxhip_gemm_fp8_mx(const fluxhip_gemm_desc* d, const fluxhip_fp8_scales* sc, const fluxhip_fp8_mx* mx, void* stream);
 /* x bf16 [rows][ld] (K columns) -> e4m3 out[rows][ld_out] at column col0 + block scales (tiling above; scale-buffer row =
  * row0 + r).  K % 32 == 0, col0 % 32 == 0, row0 % 64 == 0, ld % 8 == 0, ld_out % 8 == 0. */

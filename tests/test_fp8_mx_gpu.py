@@ -44,7 +44,7 @@ def test_quantize_mx_bit_exact(dev, rows, K, col0, row0):
     assert int(q[:, :col0].sum()) == 0                      # columns before col0 untouched
 
 
-@pytest.mark.parametrize("cfg", [0, 49, 50, 51, 52])
+@pytest.mark.parametrize("cfg", [0, 49, 50, 51, 52, 53, 55])
 @pytest.mark.parametrize("M,N,K", [(320, 3072, 3072), (1280, 3072, 12288), (4352, 3072, 15360)])
 def test_gemm_mxa_vs_dequantised_product(dev, M, N, K, cfg):
     from flux_generator_amd import ops
@@ -92,7 +92,7 @@ def test_gemm_mxa_two_groups_batched(dev):
     assert rel_l2(out, want) <= 4e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 49, 51, 52])
+@pytest.mark.parametrize("cfg", [0, 49, 51, 52, 53, 55])
 @pytest.mark.parametrize("M,N,K", [(320, 512, 1024), (1280, 12288, 3072)])
 def test_gemm_gelu_mxc_epilogue(dev, M, N, K, cfg):
     from flux_generator_amd import ops
