@@ -1389,7 +1389,7 @@ void gemm_nt_kernel(const GemmParams p) {
     } else if (!LEAN && epi == EPI_SILU) {
       for (int r = 0; r < NV; ++r) v[r] = silu_f(v[r]);
     } else if (!LEAN && epi == EPI_QUICK_GELU) {
-      for (int r = 0; r < NV; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+      for (int r = 0; r < NV; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[r]));
     } else if (!LEAN && epi == EPI_GELU_ERF) {
       for (int r = 0; r < NV; ++r) v[r] = gelu_erf_f(v[r]);
     } else if (epi == EPI_GATE_RES) {

@@ -322,10 +322,22 @@ class FluxPipeline:
         for k, v in weights.items():
             if k.endswith(".lora_a") and rank and v.shape[1] != rank:
                 raise ValueError(f"{k}: rank {v.shape[1]} does not match the adapter's lora_rank {rank}")
-        if fuse:
-            # in place on the weight tensors: captured hipGraphs keep pointing at the (now updated) weights
+        if fuse or self.flow.fp8:
+            # in place on the weight tensors: captured hipGraphs keep pointing at the (now updated) weights.  An adapter loaded
+            # AFTER --quantize is folded as well (the fp8 plan carries no separate branch; Flux.enable_fp8 says the same).
+            if not fuse:
+                import warnings
+                warnings.warn("load_adapter: the flow model runs the fp8 plan - the adapter is folded into the weights")
             return self.flow.fuse_lora(weights, scale=1.0)      # LoRALinear.from_base default scale (flux/lora.py:15)
-        return self.flow.attach_lora(weights, scale=1.0)          # (plan_epoch bump: stale step graphs are dropped)
+        # The reference wraps EVERY nn.Linear of a block (linear_to_lora_layers, flux/flux.py:229-239), the modulation Linears
+        # included, and dreambooth.py saves them all.  Block Linears keep their separate low-rank branch; the modulation
+        # Linears are rows of the one concatenated GEMV table evaluated once per image, so their update is folded into the
+        # table (bf16, like LoRALinear.fuse) - the only deviation from the unfused reference, of the size of one bf16 rounding
+        # of those weights.
+        branch, fold = self.flow.splits_for_adapter(weights)
+        n = self.flow.fuse_lora(fold, scale=1.0) if fold else 0
+        self.adapter_layers = dict(branches=len(branch) // 2, folded=n)
+        return n + self.flow.attach_lora(branch, scale=1.0)     # (plan_epoch bump: stale step graphs are dropped)
 
     def generate(self, *args, **kwargs):
         """Alias of generate_images (BASELINE.json north_star wording)."""

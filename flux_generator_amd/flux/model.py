@@ -221,7 +221,13 @@ class Flux:
         (include/fluxhip.h, fluxhip_gemm_fp8).  The residual stream, norms, modulation, attention and the small
         embedders stay bf16.  Weights are quantised once, here; launch plans are rebuilt."""
         if enabled and self._lora:
-            raise ValueError("unfused LoRA branches run on the bf16 plan: fuse_lora the adapter before enable_fp8()")
+            # The reference quantises LoRALinear.linear and keeps the low-rank branch (nn.quantize walks into the wrapper);
+            # the fp8 plan here has no matrix-addend epilogue, so the branches are folded into W first (W + scale B^T A^T in
+            # bf16, LoRALinear.fuse) - the result the reference gets with --fuse-adapter --quantize.  Stated, not silent.
+            import warnings
+            warnings.warn(f"enable_fp8: folding {len(self._lora)} unfused LoRA branches into the weights before quantising "
+                          "(the fp8 plan carries no separate low-rank branch)")
+            self.fuse_attached_lora()
         if enabled and not self._w8:
             for name, w in self._params.items():
                 if name.endswith(".weight") and name[: -len(".weight")].endswith(self._FP8_LAYERS) and w.dim() == 2:
@@ -264,7 +270,38 @@ class Flux:
         torch.cuda.synchronize(self.device)
         return len(names)
 
-    LORA_PAD = 64        # the rank is zero-padded to one K-step of the GEMM (exact: the padding multiplies zeros)
+    def fuse_attached_lora(self) -> int:
+        """Fold the branches `attach_lora` keeps separate into the weights (LoRALinear.fuse, flux/lora.py:28-43) and drop them:
+        W <- W + (scale * B^T A^T).astype(bf16), the same in-place GEMM as `fuse_lora`.  Returns the number of layers folded."""
+        n_l = len(self._lora)
+        for n, (at, bt, sc) in self._lora.items():
+            W = self._params[f"{n}.weight"]
+            out_d, in_d = W.shape
+            ap = at.t().contiguous()                          # [in, pad]: the "weight" operand of the update GEMM
+            ops.gemm(make_gemm_desc([dict(A=bt.data_ptr(), W=ap.data_ptr(), C=W.data_ptr(), res=W.data_ptr(), M=out_d)],
+                                    1, in_d, ap.shape[1], ap.shape[1], in_d, EPI_GATE_RES, alpha=float(sc)))
+            if n in self._w8:
+                ops.quantize_rows_fp8(W, out=self._w8[n][0], scale=self._w8[n][1])
+        torch.cuda.synchronize(self.device)
+        if n_l:
+            self._lora = {}
+            self._lora_zero.clear()
+            self._ws.clear()
+            self.plan_epoch += 1
+        return n_l
+
+    LORA_PAD = 64        # the rank is zero-padded to whole K-steps of the GEMM (exact: the padding multiplies zeros); attach_lora
+                         # raises the instance's value to ceil(max rank / 64) * 64 (dreambooth.py --lora-rank is unbounded)
+
+    def splits_for_adapter(self, adapter: Dict[str, torch.Tensor]):
+        """(branch, fold): the adapter's entries that can run as unfused low-rank branches (the blocks' qkv / proj / MLP /
+        linear1 / linear2 Linears) and those that cannot (the modulation Linears the reference's linear_to_lora_layers also
+        wraps, flux/flux.py:229-239: here they are rows of ONE concatenated GEMV table, evaluated once per image)."""
+        branch, fold = {}, {}
+        for k, v in adapter.items():
+            n = k.rsplit(".", 1)[0]
+            (branch if (n not in self.mod_off and n.endswith(self._FP8_LAYERS)) else fold)[k] = v
+        return branch, fold
 
     def attach_lora(self, adapter: Dict[str, torch.Tensor], scale: float = 1.0) -> int:
         """LoRA adapters kept as SEPARATE low-rank branches — what the reference runs when `--fuse-adapter` is absent
@@ -284,24 +321,27 @@ class Flux:
                 raise ValueError(f"adapter targets unknown layer {n}")
             if n in self.mod_off or not n.endswith(self._FP8_LAYERS):
                 raise ValueError(f"{n}: only the blocks' qkv / proj / MLP / linear1 / linear2 Linears run an unfused branch; "
-                                 "fold this one with fuse_lora")
+                                 "fold this one with fuse_lora (FluxPipeline.load_adapter does: Flux.splits_for_adapter)")
         if self.fp8 and names:
-            raise ValueError("unfused LoRA branches run on the bf16 plan: enable_fp8(False) first, or fuse_lora")
+            raise ValueError("unfused LoRA branches run on the bf16 plan: enable_fp8(False) first, or fuse_lora "
+                             "(FluxPipeline.load_adapter folds by itself when the flow model is already quantised)")
         lora = {}
+        pad = max([64] + [(adapter[f"{n}.lora_a"].shape[1] + 63) // 64 * 64 for n in names])
         for n in names:
             W = self._params[f"{n}.weight"]
             a, b = adapter[f"{n}.lora_a"], adapter[f"{n}.lora_b"]
             out_d, in_d = W.shape
             r = a.shape[1]
-            if tuple(a.shape) != (in_d, r) or tuple(b.shape) != (r, out_d) or r > self.LORA_PAD:
-                raise ValueError(f"Shape mismatch for {n}: lora_a {tuple(a.shape)}, lora_b {tuple(b.shape)}, weight {tuple(W.shape)} "
-                                 f"(rank <= {self.LORA_PAD})")
-            at = torch.zeros(self.LORA_PAD, in_d, dtype=BF16, device=self.device)     # rows = rank: the "weight" of u = x A
+            if tuple(a.shape) != (in_d, r) or tuple(b.shape) != (r, out_d):
+                raise ValueError(f"Shape mismatch for {n}: lora_a {tuple(a.shape)}, lora_b {tuple(b.shape)}, weight {tuple(W.shape)}")
+            at = torch.zeros(pad, in_d, dtype=BF16, device=self.device)     # rows = rank: the "weight" of u = x A
             at[:r] = a.to(device=self.device, dtype=BF16).t()
-            bt = torch.zeros(out_d, self.LORA_PAD, dtype=BF16, device=self.device)    # [out, rank]: the "weight" of z = u B
+            bt = torch.zeros(out_d, pad, dtype=BF16, device=self.device)    # [out, rank]: the "weight" of z = u B
             bt[:, :r] = b.to(device=self.device, dtype=BF16).t()
             lora[n] = (at, bt, float(scale))
         self._lora = lora
+        self.LORA_PAD = pad
+        self._lora_zero.clear()
         self._ws.clear()
         self.plan_epoch += 1
         return len(names)

@@ -79,3 +79,55 @@ def test_product_path_has_no_oracle_or_cpu_fallback():
     from flux_generator_amd.flux.model import Flux, FluxParams
     with pytest.raises(ops.FluxHipError):
         Flux(FluxParams(64, 64, 128, 256, 4.0, 2, 1, 1, [16, 56, 56], 10000, True, False), device="cpu")
+
+
+def test_integration_stub_matches_the_header():
+    """INTEGRATION.md's ctypes stub is executed as written (the library path comes from FLUXHIP_LIB, as the stub says) and
+    every struct it declares must have the size and the field offsets of the loader's mirror of include/fluxhip.h; the
+    ABI version its prose quotes must be the header's.  A maintainer pasting a stale stub would hand under-sized structs
+    to fluxhip_gemm_bf16 (round-4 review: the doc had drifted two ABI versions behind)."""
+    from flux_generator_amd import _lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(# fluxhip_binding\.py.*?)```", doc, flags=re.S)
+    assert m, "INTEGRATION.md lost its binding stub"
+    hdr = open(os.path.join(ROOT, "include", "fluxhip.h")).read()
+    abi = int(re.search(r"#define\s+FLUXHIP_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert re.search(rf"`FLUXHIP_ABI_VERSION` is {abi}\b", doc), "INTEGRATION.md quotes another ABI version than the header"
+    old = os.environ.get("FLUXHIP_LIB")
+    os.environ["FLUXHIP_LIB"] = str(_lib.LIB_PATH)
+    ns = {}
+    try:
+        exec(compile(m.group(1), "INTEGRATION.md:stub", "exec"), ns)      # loads the library, asserts its ABI, declares the structs
+    finally:
+        if old is None:
+            os.environ.pop("FLUXHIP_LIB", None)
+        else:
+            os.environ["FLUXHIP_LIB"] = old
+    for name in ("GemmGroup", "GemmDesc"):
+        doc_t, lib_t = ns[name], getattr(_lib, name)
+        assert ctypes.sizeof(doc_t) == ctypes.sizeof(lib_t), name
+        assert [f[0] for f in doc_t._fields_] == [f[0] for f in lib_t._fields_], name
+        for f in doc_t._fields_:
+            assert getattr(doc_t, f[0]).offset == getattr(lib_t, f[0]).offset, (name, f[0])
+            assert getattr(doc_t, f[0]).size == getattr(lib_t, f[0]).size, (name, f[0])
+    # the argtypes the stub sets are the loader's
+    for fn in ("fluxhip_gemm_bf16", "fluxhip_attention_d128_bf16"):
+        got = getattr(ns["_lib"], fn).argtypes
+        want = _lib.SIGNATURES[fn][1]
+        assert len(got) == len(want), fn
+        for a, b in zip(got, want):
+            assert ctypes.sizeof(a) == ctypes.sizeof(b), fn
+    # the header's structs themselves, compiled: sizeof from the C compiler = the ctypes mirror
+    import shutil, subprocess, tempfile
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc:
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "sz.c")
+            open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "fluxhip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+                                 'sizeof(fluxhip_gemm_group),sizeof(fluxhip_gemm_desc),offsetof(fluxhip_gemm_group,add),'
+                                 'offsetof(fluxhip_gemm_desc,ld_add),sizeof(fluxhip_fp8_mx));return 0;}\n')
+            exe = os.path.join(td, "sz")
+            subprocess.check_call([cc, "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+            out = subprocess.check_output([exe], text=True).split()
+        assert [int(v) for v in out] == [ctypes.sizeof(_lib.GemmGroup), ctypes.sizeof(_lib.GemmDesc), _lib.GemmGroup.add.offset,
+                                         _lib.GemmDesc.ld_add.offset, ctypes.sizeof(_lib.Fp8Mx)]

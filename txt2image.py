@@ -79,13 +79,21 @@ def main(argv=None):
     dev = flux.device
     if args.adapter:
         n = flux.load_adapter(args.adapter, fuse=args.fuse_adapter)
-        print(f"Applied LoRA adapter {args.adapter} to {n} layers "
-              f"({'folded into the weights' if args.fuse_adapter else 'separate low-rank branches, like the unfused LoRALinear'})",
-              file=sys.stderr)
+        how = "folded into the weights"
+        if not args.fuse_adapter:
+            al = getattr(flux, "adapter_layers", None) or dict(branches=n, folded=0)
+            how = (f"{al['branches']} separate low-rank branches, like the unfused LoRALinear"
+                   + (f"; {al['folded']} modulation Linears folded into the modulation table" if al["folded"] else ""))
+            if args.quantize:
+                how += "; --quantize folds the branches before quantising (the fp8 plan carries no separate branch)"
+        print(f"Applied LoRA adapter {args.adapter} to {n} layers ({how})", file=sys.stderr)
     if args.quantize:
         # the reference's nn.quantize (txt2image.py:79-82) re-designed for CDNA4: e4m3 weights (per output channel) and
         # e4m3 activations (per token / block-scaled) of the transformer blocks' Linears on the fp8 matrix cores
-        flux.flow.enable_fp8()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # (the folding of unfused branches is announced above)
+            flux.flow.enable_fp8()
         flux.quantize_text()
         print("--quantize: fp8 e4m3 Linears in the flow transformer's blocks, the T5 encoder (all but the value projection) and "
               "CLIP (second MLP Linear: the reference's in_dim % 512 predicate); the VAE keeps float32", file=sys.stderr)
