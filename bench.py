@@ -284,6 +284,21 @@ def dry_run(args) -> None:
     dist.destroy_process_group()
 
 
+def parity_full_size_record():
+    """The committed full-size parity numbers (not re-measured by the bench: the oracle forwards take minutes of host time):
+    what `pytest tests/test_full_size_parity_gpu.py` measured for this tree on a GPU box, copied to profiles/ by the round's
+    profile script.  Every number is against an oracle whose parity with the MLX reference is UNPINNED (oracle/UNVERIFIED.md)."""
+    for name in ("r05_parity_full_size.json", "r04_parity_full_size.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                rec = json.load(f)
+            rec["source"] = f"profiles/{name} (committed; measured by tests/test_full_size_parity_gpu.py, rel-L2 unless named otherwise)"
+            rec["oracle"] = "oracle/flux_oracle.py, oracle/sd_oracle.py: CPU restatement of the reference, parity with MLX unpinned"
+            return rec
+    return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -521,7 +536,8 @@ def main() -> None:
                        "vae_decode_ms_bf16_storage_optin": decode_ms["bf16"],
                        "flux_forward_tflop_per_image": fwd_tflop, "denoise_mfma_frac": B * fwd_tflop / (step_ms * 1e-3) / peak,
                        "denoise_mfma_frac_in_loop": (B * fwd_tflop / ((step_ms_loop + mod_ms / args.denoise_steps) * 1e-3) / peak) if step_ms_loop else None,
-                       "hip_graph": not args.no_graph, "kernel_breakdown_one_forward": breakdown},
+                       "hip_graph": not args.no_graph, "kernel_breakdown_one_forward": breakdown,
+                       "parity_full_size": parity_full_size_record()},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

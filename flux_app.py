@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """A1111 / Open-WebUI compatible image API over the MI355X pipelines — the HTTP surface of the
 reference's flux_app.py (routes and JSON shapes of :47-62,:90-321; server flags of :786-793).
-The Gradio UI and the MusicGen tab are out of scope; the Darwin/arm64 gate is replaced by a ROCm check."""
+The Gradio UI and the MusicGen tab are out of scope; the Darwin/arm64 gate is replaced by a ROCm check.
+
+More than one GPU:  `torchrun --nproc-per-node N --master-addr 127.0.0.1 flux_app.py [--port P]`.  Rank 0 serves HTTP; ranks
+1..N-1 sit in `worker_loop`.  A request's `batch_size * n_iter` images (the reference generates them as one batch,
+flux_app.py:123-204) are sharded by image over the N ranks: rank 0 broadcasts the request, every rank builds / reuses the same
+pipeline, the pipelines' own sharded `generate_latents` (rank-0 text conditioning broadcast over RCCL, same-seed prior slice,
+no collective inside a step) and `gather_images` (uint8 to rank 0) do the rest - the path `torchrun txt2image.py` takes."""
 import argparse
 import base64
 import io
@@ -70,12 +76,69 @@ class FluxAPI:
                         steps: Optional[int] = None, guidance: float = 4.0, seed: Optional[int] = None,
                         batch_size: int = 1, n_iter: int = 1, return_pil: bool = False):
         with self._lock:
+            if _dist_world()[1] > 1:
+                # rank 0 of a torchrun job: hand the request to the worker ranks (they block in worker_loop), then run it too
+                req = dict(prompt=prompt, model=model, width=width, height=height, steps=steps, guidance=guidance, seed=seed,
+                           batch_size=batch_size, n_iter=n_iter)
+                _bcast_obj(req)
+                return self._generate_sharded(return_pil=return_pil, **req)
             return self._generate_images(prompt, model, width, height, steps, guidance, seed, batch_size, n_iter, return_pil)
 
-    def _generate_images(self, prompt, model, width, height, steps, guidance, seed, batch_size, n_iter, return_pil):
-        import numpy as np
+    def _generate_sharded(self, prompt, model, width, height, steps, guidance, seed, batch_size, n_iter, return_pil=False):
+        """One request on every rank of the job (rank 0: called from the route; ranks > 0: from worker_loop).  Returns the
+        encoded images on rank 0, None elsewhere.  A rank that cannot build the pipeline (missing checkpoint ...) must not
+        leave the others waiting inside a collective: the outcome of init_pipeline is agreed on first."""
         import torch
+        rank, world = _dist_world()
+        err = None
+        try:
+            pipe = self.init_pipeline(model)
+        except Exception as e:                   # noqa: BLE001 - reported to every rank below
+            err, pipe = e, None
+        if not _all_ok(err is None):
+            raise err if err is not None else RuntimeError("another rank of the job could not build the pipeline")
+        n = batch_size * n_iter
+        latent_size = (height // 8, width // 8)
+        sd = model.startswith("stabilityai/")
+        if sd:
+            steps = steps or (2 if "sdxl-turbo" in model else 50)
+            guidance = guidance or (0.0 if "sdxl-turbo" in model else 7.5)
+            latents = pipe.generate_latents(prompt, n_images=n, cfg_weight=guidance, num_steps=steps, seed=seed)
+            out_hw = (512, 512)                  # (the reference does not pass latent_size on this route: always 64 x 64 latents)
+        else:
+            steps = steps or (50 if model == "flux-dev" else 2)
+            latents = pipe.generate_latents(prompt, n_images=n, num_steps=steps, latent_size=latent_size,
+                                            guidance=guidance, seed=seed)
+            next(latents)                        # conditioning tuple (computed on rank 0, broadcast)
+            out_hw = (latent_size[0] * 8, latent_size[1] * 8)
+        x_t = None
+        for x_t in latents:                      # this rank's rows of the batch (pipe.shard); possibly none when n < world
+            pass
+        imgs = [pipe.decode(x_t[i:i + self.DECODE_BATCH]) if sd else pipe.decode(x_t[i:i + self.DECODE_BATCH], latent_size)
+                for i in range(0, len(x_t), self.DECODE_BATCH)]
+        local = torch.cat(imgs, dim=0) if imgs else torch.empty(0, *out_hw, 3, device=x_t.device)
+        allimg = pipe.gather_images(local, n)    # uint8 [n, H, W, 3] on rank 0 (batch order), None elsewhere
+        if allimg is None:
+            return None
+        return self._encode(list(allimg.cpu().numpy()), return_pil)
+
+    @staticmethod
+    def _encode(arrs, return_pil):
+        import numpy as np
         from PIL import Image
+        out = []
+        for arr in arrs:
+            pil = Image.fromarray(np.asarray(arr))
+            if return_pil:
+                out.append(pil)
+            else:
+                buf = io.BytesIO()
+                pil.save(buf, format="PNG")
+                out.append(base64.b64encode(buf.getvalue()).decode())
+        return out
+
+    def _generate_images(self, prompt, model, width, height, steps, guidance, seed, batch_size, n_iter, return_pil):
+        import torch
         pipe = self.init_pipeline(model)
         n = batch_size * n_iter
         latent_size = (height // 8, width // 8)
@@ -92,7 +155,6 @@ class FluxAPI:
         x_t = None
         for x_t in latents:
             pass
-        out = []
         # decode in batches (the reference decodes one image at a time, flux_app.py:186-192): up to DECODE_BATCH latents per
         # VAE pass, one device->host copy per batch; float -> uint8 by truncation like the reference
         arrs = []
@@ -100,15 +162,7 @@ class FluxAPI:
             chunk = x_t[i:i + self.DECODE_BATCH]
             img = pipe.decode(chunk) if sd else pipe.decode(chunk, latent_size)
             arrs.extend((img * 255).to(torch.uint8).cpu().numpy())
-        for arr in arrs:
-            pil = Image.fromarray(np.asarray(arr))
-            if return_pil:
-                out.append(pil)
-            else:
-                buf = io.BytesIO()
-                pil.save(buf, format="PNG")
-                out.append(base64.b64encode(buf.getvalue()).decode())
-        return out
+        return self._encode(arrs, return_pil)
 
     async def txt2img(self, request: SDAPIRequest) -> SDAPIResponse:
         try:
@@ -128,10 +182,10 @@ class FluxAPI:
 
     def get_options(self):
         order = (0, 2, 1, 3)
-        # "sd_backend" is the reference's literal (Open-WebUI reads it); "sd_device" is an addition: this server process drives
-        # ONE GPU (libfluxhip binds one device per process); batches over several GPUs go through `torchrun txt2image.py`
+        # "sd_backend" is the reference's literal (Open-WebUI reads it); "sd_device" is an addition: one process drives ONE GPU
+        # (libfluxhip binds one device per process); under `torchrun flux_app.py` the job's ranks share every request
         return {"sd_model_checkpoint": "stabilityai/stable-diffusion-2-1-base", "sd_backend": "Flux MLX",
-                "sd_device": "1 x MI355X per server process",
+                "sd_device": f"{_dist_world()[1]} x MI355X (one process per GPU; a request's images are sharded over them)",
                 "sd_model_list": [dict(title=_MODELS[i][1], name=_MODELS[i][0], model_name=_MODELS[i][0]) for i in order]}
 
     def set_options(self, options: dict):
@@ -141,6 +195,60 @@ class FluxAPI:
         return {"progress": 0, "eta_relative": 0,
                 "state": {"skipped": False, "interrupted": False, "job": "", "job_count": 0, "job_timestamp": ""},
                 "current_image": None, "textinfo": "Idle"}
+
+
+def _dist_world():
+    """(rank, world size) of the torch.distributed job this server belongs to; (0, 1) for a plain `python flux_app.py`."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:            # pragma: no cover
+        pass
+    return 0, 1
+
+
+def _bcast_obj(obj, src: int = 0):
+    """Rank `src` passes the object, the other ranks pass None and receive it (a request dict; None = shut down)."""
+    import torch.distributed as dist
+    box = [obj]
+    if dist.get_backend() == "nccl":       # RCCL moves device memory: the pickled bytes travel through the rank's GPU
+        import torch
+        dist.broadcast_object_list(box, src=src, device=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def _all_ok(ok: bool) -> bool:
+    """True iff every rank reports ok (one tiny all-reduce; keeps a failing rank from desynchronising the job)."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(t)
+    return int(t.item()) == 0
+
+
+def worker_loop(api_: "FluxAPI") -> int:
+    """Ranks 1..N-1 of `torchrun flux_app.py`: wait for rank 0 to broadcast a request, run this rank's share of it, repeat
+    until rank 0 broadcasts None (server shutdown).  Returns the number of requests served."""
+    served = 0
+    while True:
+        req = _bcast_obj(None)
+        if req is None:
+            return served
+        try:
+            api_._generate_sharded(**req)
+        except Exception as e:       # noqa: BLE001 - rank 0 reports the failure to the client (HTTP 500); keep serving
+            print(f"[flux_app worker rank {_dist_world()[0]}] request failed: {e}", file=sys.stderr)
+        served += 1
+
+
+def shutdown_workers() -> None:
+    rank, world = _dist_world()
+    if rank == 0 and world > 1:
+        _bcast_obj(None)
 
 
 api = FluxAPI()
@@ -232,13 +340,32 @@ def main():
         parser.add_mutually_exclusive_group().add_argument("--listen-all", action="store_true",
                                                            help="Listen on all network interfaces (0.0.0.0)")
         args = parser.parse_args()
+        import os
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:                  # torchrun: one process per GPU, rank 0 serves, the others work
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+            torch.cuda.set_device(device)
+            if not dist.is_initialized():
+                dist.init_process_group("nccl", device_id=torch.device(device))
+            if dist.get_rank() != 0:
+                n = worker_loop(api)
+                print(f"[flux_app worker rank {dist.get_rank()}] served {n} requests, exiting")
+                dist.destroy_process_group()
+                return
         host = "0.0.0.0" if args.listen_all else "127.0.0.1"
         port = args.port if check_port_available(host, args.port) else find_available_port(host, args.port)
         if port != args.port:
             print(f"Warning: Port {args.port} is in use, using port {port} instead")
         print(f"Starting Flux server on {host}:{port}")
         import uvicorn
-        uvicorn.Server(uvicorn.Config(get_app(), host=host, port=port, log_level="info")).run()
+        try:
+            uvicorn.Server(uvicorn.Config(get_app(), host=host, port=port, log_level="info")).run()
+        finally:
+            shutdown_workers()       # (no-op for a single process) the worker ranks leave their loop
     except SystemError as e:
         print(f"Error: {e}")
         sys.exit(1)

@@ -109,45 +109,82 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
     qf[ds] = *(const bf16x8*)(Qh + (long long)qrow * p.q_rs + ds * 16 + hi * 8);
 
   // staging sources
+  // Round 5: every LDS-DMA piece is addressed as (wave-uniform 64-bit base of the STAGE) + (32-bit lane offset that does not
+  // change from stage to stage) - the saddr form of global_load_lds.  The per-piece address used to be rebuilt from the key
+  // index every time: min / sign-extend / two quarter-rate 32-bit multiplies / 64-bit multiply-add / shift-add per K piece and a
+  // 64-bit compare / select chain per V^T piece, ~185 VALU + ~100 SALU instructions per KV tile and wave next to the ~130 the
+  // softmax itself needs, in a kernel that is bound by instruction issue.  Only a stage that reaches past Tk /
+  // Tkpad (the last one, when Tk is not a multiple of KS * 64) needs clamped per-lane keys: its offsets are rebuilt once, against
+  // the head's base (uniform branch, never taken for the Flux shapes).  The launcher checks that a head's K / V^T image is < 4 GiB.
   const int kr = lane / CPR, kc = lane % CPR;   // K piece: KROWS rows x CPR chunks
   const int vr = lane >> 3, vc = lane & 7;      // V^T piece: 8 rows x 8 chunks
   // piece id = wave + i * (NW*KS): tile = id / pieces-per-tile, piece inside the tile = id % pieces-per-tile
-  const char* vsrc[VPW];
-  int krow[KPW], kchunk[KPW];
+  const uint32_t k_rowbytes = (uint32_t)(p.k_rs * 2), v_rowbytes = (uint32_t)Tkpad * 2u;
+  auto k_piece = [&](int i, int& krow_, int& chunk_) {      // key row of this lane inside the stage, swizzled source chunk
+    const int id = wave + i * (NW * KS);
+    const int row = (id % PPT_K) * KROWS + kr;
+    krow_ = row + (id / PPT_K) * KV;
+    chunk_ = kc ^ (HD == 128 ? (row & 15) : ((row >> 1) & 7));
+  };
+  auto v_piece = [&](int i, int& d_, int& chunk_, int& tile_) {
+    const int id = wave + i * (NW * KS);
+    d_ = (id % PPT_V) * 8 + vr;
+    chunk_ = vc ^ ((d_ >> 1) & 7);
+    tile_ = id / PPT_V;
+  };
+  uint32_t koffs[KPW], voffs[VPW];
 #pragma unroll
   for (int i = 0; i < KPW; ++i) {
-    const int id = wave + i * (NW * KS);
-    int row = (id % PPT_K) * KROWS + kr;
-    krow[i] = row + (id / PPT_K) * KV;          // + tile offset in keys
-    kchunk[i] = kc ^ (HD == 128 ? (row & 15) : ((row >> 1) & 7));
+    int kr_, ch_;
+    k_piece(i, kr_, ch_);
+    koffs[i] = (uint32_t)kr_ * k_rowbytes + ch_ * 16;
   }
 #pragma unroll
   for (int i = 0; i < VPW; ++i) {
-    const int id = wave + i * (NW * KS);
-    int d = (id % PPT_V) * 8 + vr;
-    int lchunk = vc ^ ((d >> 1) & 7);
-    vsrc[i] = (const char*)(Vh + (long long)d * Tkpad) + lchunk * 16 + (id / PPT_V) * (KV * 2);
+    int d_, ch_, t_;
+    v_piece(i, d_, ch_, t_);
+    voffs[i] = (uint32_t)d_ * v_rowbytes + ch_ * 16 + t_ * (KV * 2);
   }
-  // one stage = KS consecutive KV tiles: [KS][K tile | V^T tile]
-  // [p0, p1): which of this wave's KPW + VPW pieces to issue (the main loop issues one between MFMAs)
-  auto stage = [&](int it, int buf, int p0 = 0, int p1 = 64) {
-    char* s0 = smem + buf * (KS * STAGE);
+  const char* kbase = (const char*)Kh;          // wave-uniform bases of the stage being issued (stage_addr)
+  const char* vbase = (const char*)Vh;
+  auto stage_addr = [&](int it) {
     const int key0 = it * (KS * KV);
+    if (key0 + KS * KV <= Tk) {
+      kbase = (const char*)Kh + (long long)key0 * p.k_rs * 2;
+      vbase = (const char*)Vh + (long long)key0 * 2;
+    } else {                                    // keys past Tk - 1 re-read row Tk - 1 (masked later); V^T tiles stay inside the row
+      kbase = (const char*)Kh;
+      vbase = (const char*)Vh;
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        int kr_, ch_;
+        k_piece(i, kr_, ch_);
+        koffs[i] = (uint32_t)min(key0 + kr_, Tk - 1) * k_rowbytes + ch_ * 16;
+      }
+#pragma unroll
+      for (int i = 0; i < VPW; ++i) {
+        int d_, ch_, t_;
+        v_piece(i, d_, ch_, t_);
+        // (a V^T tile past Tkpad is only ever read for fully masked keys; clamp the source inside the row)
+        voffs[i] = (uint32_t)d_ * v_rowbytes + ch_ * 16 + (uint32_t)min(key0 + t_ * KV, Tkpad - KV) * 2;
+      }
+    }
+  };
+  // one stage = KS consecutive KV tiles: [KS][K tile | V^T tile]
+  // [p0, p1): which of this wave's KPW + VPW pieces to issue (the main loop issues one between MFMAs); stage_addr(it) first
+  auto stage = [&](int buf, int p0 = 0, int p1 = 64) {
+    char* s0 = smem + buf * (KS * STAGE);
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
       if (i < p0 || i >= p1) continue;
       const int id = wave + i * (NW * KS);
-      int key = min(key0 + krow[i], Tk - 1);
-      glds16((const char*)(Kh + (long long)key * p.k_rs) + kchunk[i] * 16,
-             s0 + (id / PPT_K) * STAGE + (id % PPT_K) * 1024);
+      glds16(kbase + (size_t)koffs[i], s0 + (id / PPT_K) * STAGE + (id % PPT_K) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < VPW; ++i) {
       if (KPW + i < p0 || KPW + i >= p1) continue;
       const int id = wave + i * (NW * KS);
-      // (a V^T tile past Tkpad is only ever read for fully masked keys; clamp the source inside the row)
-      const long long koff = min((long long)key0 + (id / PPT_V) * KV, (long long)Tkpad - KV) - (id / PPT_V) * KV;
-      glds16(vsrc[i] + koff * 2, s0 + (id / PPT_V) * STAGE + KT_BYTES + (id % PPT_V) * 1024);
+      glds16(vbase + (size_t)voffs[i], s0 + (id / PPT_V) * STAGE + KT_BYTES + (id % PPT_V) * 1024);
     }
   };
 
@@ -179,7 +216,8 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
   if (MODE == 2) ntiles = min(ntiles, min(qb * (NW * 32) + NW * 32 - 1, Tq - 1) / KV + 1);
   const float scale_log2 = (MODE == 1) ? 1.4426950408889634f : p.scale_log2;
   const bf16_t* bias_q = (MODE == 1) ? p.bias + ((long long)h * Tq + qrow) * Tk : nullptr;
-  stage(0, 0);
+  stage_addr(0);
+  stage(0);
   wait_vm0();
   __syncthreads();
 
@@ -192,7 +230,8 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
     const int cur = st & 1;
     const bool more = st + 1 < nstages;
     static_assert(KPW + VPW == NDS, "one LDS-DMA piece per d-step of the S product");
-    if (more && !(KS == 1 || st * KS + kp < ntiles)) stage(st + 1, cur ^ 1);   // idle wave set: no MFMAs to hide behind
+    if (more) stage_addr(st + 1);
+    if (more && !(KS == 1 || st * KS + kp < ntiles)) stage(cur ^ 1);   // idle wave set: no MFMAs to hide behind
     const int it = st * KS + kp;                 // this wave's KV tile
     const char* sk = smem + cur * (KS * STAGE) + kp * STAGE;
     const char* sv = sk + KT_BYTES;
@@ -223,7 +262,7 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
       // next stage's K / V^T pieces, one per d-step: issued back to back after the barrier they cost every
       // wave ~1000 cycles per stage in the address path with the MFMA pipe idle
       __builtin_amdgcn_sched_barrier(0);
-      if (more) stage(st + 1, cur ^ 1, ds, ds + 1);
+      if (more) stage(cur ^ 1, ds, ds + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     // V^T fragments of key block 0 travel while the softmax runs (P register pair 8j+e <-> k-slot e)
@@ -856,6 +895,8 @@ int launch_attn(const AttnParams& p, int B, hipStream_t s) {
   constexpr int NW = 4;
   constexpr int lds = 2 * KS * (KV * HD * 2 + HD * KV * 2);
   auto fn = attn_kernel<HD, NW, MODE, KS, VP, F16, MXO>;
+  // the staging addresses are 32-bit lane offsets from a per-head base (see attn_kernel): one head's K / V^T image < 4 GiB
+  if ((long long)p.Tk * p.k_rs * 2 >= (1ll << 32) || (long long)HD * p.Tkpad * 2 >= (1ll << 32)) return FLUXHIP_EINVAL;
   static bool done = false;            // one flag per template instantiation
   if (!done) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)

@@ -36,12 +36,27 @@ class _LazyTower:
 class StableDiffusion:
     MAX_GRAPHS = 6      # captured hipGraphs kept (LRU): each owns a private pool of ~1-6 GB at batch 16
 
-    def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True):
+    def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True,
+                 storage: Optional[str] = None):
         # float16=True is the reference's float16 arithmetic (__init__.py:20-27; flux_app.py:77-79 passes it): UNet and text
         # towers store IEEE half and multiply on v_mfma_f32_16x16x32_f16 with fp32 accumulate / norms / softmax.
-        # float16=False: the reference computes in float32; this path then stores bfloat16 (same kernels, float32 range,
-        # 8-bit significand: rel-L2 7e-3 against float32 on the full-size UNet where float16 measures ~1e-3) - stated in
-        # DESIGN.md §5, not yet a float32-faithful UNet.  The VAE decode is float32-faithful either way.
+        # float16=False asks for the reference's FLOAT32 UNet / CLIP (__init__.py:18-23).  That arithmetic is not built here
+        # (the float32-faithful split-bf16 kernels cover the VAE decoders only), and a narrower one is not substituted
+        # silently: the constructor raises unless the caller opts into bfloat16 STORAGE by name - storage="bfloat16" (or
+        # FLUXHIP_SD_STORAGE=bfloat16): same kernels, float32 range, 8-bit significand, rel-L2 7e-3 against float32 on the
+        # full-size UNet where float16 measures ~1e-3.  The VAE decode is float32-faithful either way.
+        import os
+        storage = storage or os.environ.get("FLUXHIP_SD_STORAGE")
+        if float16:
+            if storage not in (None, "float16"):
+                raise ValueError(f"float16=True stores IEEE half; storage='{storage}' contradicts it")
+        elif storage != "bfloat16":
+            raise NotImplementedError(
+                "StableDiffusion(float16=False) is the reference's float32 UNet / text-encoder arithmetic "
+                "(stable_diffusion/__init__.py:18-23), which this engine does not implement.  Pass float16=True (IEEE half on "
+                "the f16 matrix cores: the reference's own float16 mode, what flux_app.py uses), or opt into bfloat16 storage "
+                "explicitly with storage='bfloat16' / FLUXHIP_SD_STORAGE=bfloat16 (8-bit significand: NARROWER than float32, "
+                "rel-L2 7e-3 on the full-size UNet).  The VAE decode is float32-faithful in every mode.")
         self.dtype = torch.float16 if float16 else torch.bfloat16
         self.float16 = bool(float16)
         self.device = _lib.bind_device(device)
@@ -267,8 +282,9 @@ class StableDiffusion:
 
 
 class StableDiffusionXL(StableDiffusion):
-    def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True):
-        super().__init__(model, float16, device, use_graph)
+    def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True,
+                 storage: Optional[str] = None):
+        super().__init__(model, float16, device, use_graph, storage)
         self.sampler = SimpleEulerAncestralSampler(self.diffusion_config)
         self._set_sampler_dtype()
         self._towers = {"text_encoder_1": self._towers["text_encoder"],

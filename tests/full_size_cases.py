@@ -1,0 +1,128 @@
+"""The full-size parity cases whose oracle outputs are STORED (tests/golden/full_size/*.pt) instead of recomputed in every
+`-m gpu` run: the model, the seeded inputs and the weight fingerprint of each case, shared by the generator
+(tools/make_full_size_golden.py: draws the weights on a GPU box, runs the CPU oracle once - minutes of host time per case -
+and stores the outputs) and by the tests that compare the HIP forward with the stored vectors
+(tests/test_full_size_parity_gpu.py).  A stored vector is only meaningful for the weights it was computed with, so every
+fixture carries `weight_hash` and the tests assert that the regenerated weights (device Philox stream of `init_random`,
+the fp8 quantiser for C5) hash to it.
+
+Cases (BASELINE.json configs):
+  c3  Flux-dev 1024 x 1024: S = 512, L = 4096, T = 4608, guidance 7, one forward at t = timesteps(28)[1]      configs[2]
+  c5  Flux-schnell, fp8 plan, B = 4 distinct images, S = 256, L = 4096, T = 4352, t = 0.75; the oracle runs in float32 on
+      the DE-QUANTISED weights (so what is measured is activation quantisation + bf16 storage)                    configs[4]
+  c4  SDXL UNet (2.567 B parameters), float16, B = 16 DISTINCT latents / text states; the oracle (float32) evaluates
+      images 0 and 11 of the batch                                                                               configs[3]
+References: flux/model.py:99-136, txt2image.py:79-82, stable_diffusion/stable_diffusion/unet.py:403-460."""
+import os
+
+import torch
+
+BF = torch.bfloat16
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size")
+_M61 = (1 << 61) - 1
+
+
+def weight_hash(tensors) -> int:
+    """Order-dependent fingerprint of a {name: device tensor} dict: per tensor the sum and the position-weighted sum of
+    its raw 16-bit (or 8-bit / 32-bit) words in int64, folded with a polynomial.  Computed on the device, 3 scalars per
+    tensor cross the bus."""
+    h = 0
+    for name in sorted(tensors):
+        t = tensors[name]
+        if t.dtype in (torch.bfloat16, torch.float16):
+            w = t.contiguous().view(torch.int16)
+        elif t.dtype == torch.float32:
+            w = t.contiguous().view(torch.int32)
+        else:
+            w = t.contiguous().view(torch.uint8)
+        w = w.reshape(-1).to(torch.int64)
+        idx = torch.arange(w.numel(), device=w.device, dtype=torch.int64) % 8191 + 1
+        a, b = int(w.sum()), int((w * idx).sum())
+        for v in (a, b, w.numel()):
+            h = (h * 1_000_003 + (v % _M61)) % _M61
+    return h
+
+
+def flux_inputs(P, B, S, lat, seed):
+    """Seeded (img, img_ids, txt, txt_ids, vec) of B distinct images, bf16 (CPU)."""
+    from oracle import flux_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, lat, lat, 16, generator=g).to(BF)
+    img, img_ids = O.prepare_latent_images(z)
+    txt = (torch.randn(B, S, P.context_in_dim, generator=g) * 0.5).to(BF)
+    txt_ids = torch.zeros(B, S, 3, dtype=torch.int32)
+    vec = torch.randn(B, P.vec_in_dim, generator=g).to(BF)
+    return img, img_ids, txt, txt_ids, vec
+
+
+def c3_case(dev):
+    from flux_generator_amd.flux.model import Flux
+    from flux_generator_amd.flux.utils import configs
+    from oracle import flux_oracle as O
+    P = configs["flux-dev"].params
+    flow = Flux(P, device=dev).init_random(4)
+    inputs = flux_inputs(P, 1, 512, 128, seed=2)
+    t = O.timesteps("flux-dev", 28, 4096)[1]
+    return dict(flow=flow, P=P, inputs=inputs, t=t, guidance=7.0, hash=weight_hash(flow.parameters()))
+
+
+def c3_forward(case, dev):
+    d = [a.to(dev) for a in case["inputs"]]
+    return case["flow"](d[0], d[1], d[2], d[3], torch.full((1,), case["t"], dtype=BF, device=dev), d[4],
+                        torch.full((1,), case["guidance"], dtype=BF, device=dev))
+
+
+def c5_case(dev):
+    from flux_generator_amd.flux.model import Flux
+    from flux_generator_amd.flux.utils import configs
+    P = configs["flux-schnell"].params
+    flow = Flux(P, device=dev).init_random(3)
+    flow.enable_fp8()
+    inputs = flux_inputs(P, 4, 256, 128, seed=6)
+    q = {f"{n}.q": v[0] for n, v in flow._w8.items()}
+    q.update({f"{n}.s": v[1] for n, v in flow._w8.items()})
+    return dict(flow=flow, P=P, inputs=inputs, t=0.75, hash=weight_hash(flow.parameters()) ^ weight_hash(q))
+
+
+def c5_forward(case, dev):
+    d = [a.to(dev) for a in case["inputs"]]
+    return case["flow"](d[0], d[1], d[2], d[3], torch.full((4,), case["t"], dtype=BF, device=dev), d[4])
+
+
+def sdxl_cfg():
+    """The SDXL UNet configuration (tests/test_configs_gpu.py::_sdxl_cfg; stable_diffusion/config.py:8-65)."""
+    return dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=(2, 2, 2),
+                transformer_layers_per_block=(1, 2, 10), num_attention_heads=(5, 10, 20), cross_attention_dim=(2048,) * 3,
+                norm_num_groups=32, down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"), addition_embed_type="text_time",
+                addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816)
+
+
+C4_ORACLE_IMAGES = (0, 11)
+
+
+def c4_case(dev, dtype=torch.float16):
+    from flux_generator_amd.stable_diffusion.config import UNetConfig
+    from flux_generator_amd.stable_diffusion.unet import UNetModel
+    kw = sdxl_cfg()
+    model = UNetModel(UNetConfig(**kw), device=dev, dtype=dtype).init_random(5)
+    g = torch.Generator().manual_seed(21)
+    B = 16
+    x = (torch.randn(B, 64, 64, 4, generator=g) * 0.9977).to(dtype)
+    enc = torch.randn(B, 77, 2048, generator=g).to(dtype)
+    pooled = torch.randn(B, 1280, generator=g).to(dtype)
+    tid = torch.tensor([[512, 512, 0, 0, 512, 512.0]]).repeat(B, 1)
+    t = torch.full((B,), 999.0)
+    return dict(model=model, kw=kw, x=x, enc=enc, pooled=pooled, tid=tid, t=t, hash=weight_hash(model.parameters()))
+
+
+def c4_forward(case, dev):
+    return case["model"](case["x"].to(dev), case["t"].to(dev), case["enc"].to(dev),
+                         text_time=(case["pooled"].to(dev), case["tid"].to(dev)))
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN_DIR, name)
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: generate with `python tools/make_full_size_golden.py` on a GPU box")
+    return torch.load(path, map_location="cpu")

@@ -372,6 +372,47 @@ def test_sharded_pipeline_nccl_world1(dev, monkeypatch):
         dist.destroy_process_group()
 
 
+def test_http_sharded_route_nccl_world1(dev, monkeypatch):
+    """The multi-GPU route of flux_app.py (`torchrun --nproc-per-node N flux_app.py`: request broadcast, agreed pipeline
+    start-up, the pipelines' sharded generate_latents, uint8 gather to rank 0) on a REAL RCCL process group of world size 1:
+    every collective of the route runs through RCCL on this GPU and the PNGs equal the ones the plain single-process route
+    returns for the same request.  (Two ranks: tests/test_distributed_cpu.py over gloo; no multi-GPU box to measure on.)"""
+    import socket
+    import warnings
+    import torch.distributed as dist
+    from fastapi.testclient import TestClient
+    import flux_app
+    _tiny_flux_zoo(monkeypatch)
+    monkeypatch.setattr(flux_app, "api", flux_app.FluxAPI())
+    client = TestClient(flux_app.get_app())
+    req = dict(prompt="two cats", width=128, height=128, steps=2, batch_size=3, seed=5, model="schnell")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = client.post("/sdapi/v1/txt2img", json=req)
+    assert r.status_code == 200, r.text
+    want = r.json()["images"]
+    assert len(want) == 3 and len(set(want)) == 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(dev))
+    try:
+        assert flux_app._dist_world() == (0, 1)
+        assert flux_app._bcast_obj(dict(a=1)) == dict(a=1) and flux_app._all_ok(True) and not flux_app._all_ok(False)
+        got = flux_app.api._generate_sharded(prompt=req["prompt"], model="schnell", width=128, height=128, steps=2, guidance=4.0,
+                                             seed=5, batch_size=3, n_iter=1)
+        assert got == want, "the sharded route and the single-process route disagree on the same request"
+        with pytest.raises(Exception):           # a rank that cannot build the pipeline fails the request, not the job
+            flux_app.api._generate_sharded(prompt="x", model="no-such-model", width=128, height=128, steps=2, guidance=4.0,
+                                           seed=5, batch_size=1, n_iter=1)
+        assert flux_app.api._generate_sharded(prompt=req["prompt"], model="schnell", width=128, height=128, steps=2,
+                                              guidance=4.0, seed=5, batch_size=3, n_iter=1) == want
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------ LoRA adapters at inference
 def test_lora_adapter_unfused_branch(dev, tmp_path, monkeypatch):
     """`--adapter` WITHOUT `--fuse-adapter`: the reference keeps LoRALinear layers, y = linear(x) + (scale (x A) B).astype(dtype)

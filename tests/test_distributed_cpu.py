@@ -250,3 +250,94 @@ def test_two_rank_weight_broadcast():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
+
+
+# ------------------------------------------------------------------------------------------ sharded HTTP surface
+class _StubFlux:
+    """Stand-in for FluxPipeline with the SAME sharding calls the real one makes (flux_generator_amd/parallel.py): text
+    conditioning on rank 0 only + broadcast, same-seed prior slice, per-rank decode, uint8 gather to rank 0."""
+
+    def __init__(self, rank):
+        self.rank, self.cond_calls, self.shard = rank, 0, None
+
+    def generate_latents(self, prompt, n_images=1, num_steps=2, latent_size=(8, 8), guidance=4.0, seed=None):
+        from flux_generator_amd import parallel as P
+
+        def cond():
+            self.cond_calls += 1
+            g = torch.Generator().manual_seed(len(prompt))
+            return torch.randn(1, 6, 16, generator=g), torch.randn(1, 8, generator=g)
+
+        x, txt, vec, self.shard = P.shard_generation_inputs(n_images, (*latent_size, 16), seed, "cpu", cond)
+        yield (x, None, txt, None, vec)
+        for _ in range(num_steps):
+            x = (x.float() * 0.5 + txt.float().mean() * 0.0).to(x.dtype)
+            yield x
+
+    def decode(self, x, latent_size):
+        img = torch.sigmoid(x.float()[..., :3])                                   # [n, h, w, 3] in (0, 1)
+        return img.repeat_interleave(8, dim=1).repeat_interleave(8, dim=2)        # [n, 8h, 8w, 3]
+
+    def gather_images(self, images, n_images):
+        from flux_generator_amd import parallel as P
+        return P.gather_images(P.to_uint8(images).contiguous(), n_images)
+
+
+def _worker_http(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import flux_app
+    stub = _StubFlux(rank)
+    flux_app.api.init_pipeline = lambda model: stub                # noqa: E731 - every rank builds "the same pipeline"
+    if rank != 0:
+        served = flux_app.worker_loop(flux_app.api)
+        q.put((rank, served, stub.cond_calls, None))
+    else:
+        import base64
+        import io
+        import numpy as np
+        from fastapi.testclient import TestClient
+        from PIL import Image
+        client = TestClient(flux_app.get_app())
+        got = []
+        for n, seed in ((3, 5), (1, 9)):                           # n = 1: rank 1 has no image of the request
+            r = client.post("/sdapi/v1/txt2img", json=dict(prompt="a cat", width=64, height=64, steps=2, batch_size=n, seed=seed,
+                                                           model="schnell"))
+            assert r.status_code == 200, r.text
+            imgs = [np.asarray(Image.open(io.BytesIO(base64.b64decode(b)))) for b in r.json()["images"]]
+            # what ONE process computes for the same seed: the full-batch prior, two halvings, the stub decode
+            full = torch.randn((n, 8, 8, 16), generator=torch.Generator().manual_seed(seed)).bfloat16()
+            x = full
+            for _ in range(2):
+                x = (x.float() * 0.5).to(x.dtype)
+            want = (_StubFlux(0).decode(x, (8, 8)) * 255).to(torch.uint8).numpy()
+            got.append(len(imgs) == n and all(np.array_equal(a, b) for a, b in zip(imgs, want)))
+        opts = client.get("/sdapi/v1/options").json()
+        got.append(opts["sd_device"].startswith("2 x MI355X") and opts["sd_backend"] == "Flux MLX")
+        flux_app.shutdown_workers()
+        q.put((rank, 2, stub.cond_calls, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_http_surface_shards_a_request_over_two_ranks():
+    """`torchrun --nproc-per-node 2 flux_app.py` in miniature (gloo, stub pipelines that make the real parallel.* calls):
+    rank 0 serves POST /sdapi/v1/txt2img through FastAPI's TestClient, rank 1 sits in flux_app.worker_loop; the request's
+    batch_size * n_iter images (flux_app.py:123-204 of the reference: one batch) are split by parallel.shard_range, the text
+    conditioning runs on rank 0 only, and the response carries all images in batch order, equal to the single-process result
+    of the same seed.  Unmeasured on hardware (no multi-GPU box); the RCCL world-1 twin is tests/test_configs_gpu.py."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_http, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, served0, cond0, got), (r1, served1, cond1, _) = res
+    assert got == [True, True, True], got
+    assert served1 == 2, "the worker rank must have served both requests and left its loop on shutdown"
+    assert cond0 == 2 and cond1 == 0, "text conditioning is computed on rank 0 only"

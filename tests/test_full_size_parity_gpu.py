@@ -18,13 +18,14 @@ rounding through 57 gated residual blocks at width 3072 is MEASURED (round 4, pr
   a3  decode of the final latents (fp32-faithful VAE, 64 x 64 x 16 -> 512 x 512 x 3) against oracle.pipeline_decode on
       the SAME latents                                                     max-abs <= 1/255         measured 2.5e-5
       (end to end against the all-fp32-oracle image: max-abs 1.1e-2, mean-abs 1.2e-3 — reported, not asserted)
-  b   `enable_fp8()` forward vs the fp32 oracle on the DE-QUANTISED weights   rel-L2(pred) <= 6e-2
+  b   `enable_fp8()` forward vs the fp32 oracle on the DE-QUANTISED weights   rel-L2(pred) <= 2.5e-2  measured 1.55e-2
   c   the same forward with every modulation bias drawn from U(-0.5, 0.5) (gates / shifts / scales of O(0.3), where the
       default init leaves them at O(0.03) and every block close to the identity): the residual stream then really is
       rewritten 57 times: HIP vs the float32 oracle <= 1.1 x (bf16 oracle vs float32) + 5e-4 (measured 1.534e-2 vs
       1.535e-2); HIP vs the bf16 oracle <= 2e-2 (measured 1.25e-2: the two bf16 pipelines decorrelate when the blocks do more)
-  d   FLUXHIP_FULL_ORACLE=1: Flux-dev 1024 x 1024 (T = 4608, guidance embedding), one forward, bounds of a1; and
-      test_c2_which_rounding_compounds (fp32 oracle with ONLY the residual stream rounded to bf16 between blocks)
+  d   STORED oracle outputs (tests/golden/full_size/, tools/make_full_size_golden.py): Flux-dev 1024 x 1024 (T = 4608, guidance
+      embedding), the fp8 plan at B = 4 / T = 4352 on de-quantised weights, the SDXL UNet at batch 16 - see the end of the file;
+      the `which rounding compounds` diagnostic of round 4 is a mode of that tool
 
 Both sides use the SAME weights: drawn on the GPU (`init_random`, bf16-representable), fetched to the host one tensor
 at a time while the oracle walks the blocks (`DeviceWeights`), so only one block's fp32 weights are resident
@@ -46,6 +47,8 @@ from oracle import flux_oracle as O
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 RESULTS = {}
+# bounds of the stored-oracle tests: 1.5 x the error measured when the fixtures were generated (see each fixture's `measured`)
+C3_BOUND_VS_BF16, C3_BOUND_VS_FP32, C5_BOUND, C4_BOUND = 1e-2, 2e-2, 2.5e-2, 2e-3
 
 
 class DeviceWeights(Mapping):
@@ -230,64 +233,77 @@ def test_c2_full_depth_fp8_forward(dev, schnell):
         print(f"[b] fp8 full-depth forward vs fp32 oracle on de-quantised weights: {e:.3e}  ({secs:.0f} s)")
         RESULTS["c2_fp8_forward_rel_l2_vs_dequant_fp32"] = e
         _save()
-        assert e <= 6e-2
+        assert e <= 2.5e-2          # measured 1.55e-2 (round 4), 1.5 x
     finally:
         flow.enable_fp8(False)
 
 
-@pytest.mark.skipif(os.environ.get("FLUXHIP_FULL_ORACLE") != "1", reason="FLUXHIP_FULL_ORACLE=1: one more oracle forward")
-def test_c2_which_rounding_compounds(dev, schnell):
-    """Which rounding carries the 1.4e-2 between a bf16 pipeline and the fp32 answer at depth 57?  The fp32 oracle with
-    ONE change — the residual stream (img / txt, then the joint x) rounded to bf16 after every block, everything inside a
-    block still float32 — against the plain fp32 oracle.  (The real pipelines round the stream twice per double block and
-    every op output besides, so this is a lower bound of the stream's share.)"""
-    pipe, OP, inputs = schnell["pipe"], schnell["OP"], schnell["inputs"]
-    if "ref0" not in schnell:
-        pytest.skip("needs test_c2_full_depth_forward_loop_decode's fp32 reference")
-    W = DeviceWeights(pipe.flow.parameters())
-    img, img_ids, txt, txt_ids, y = inputs
-    rb = lambda x: x.to(BF).float()      # noqa: E731
-    with torch.no_grad():
-        tt = torch.full((1,), 1.0, dtype=BF)
-        x_img = O.linear(img.float(), W["img_in.weight"], W["img_in.bias"])
-        vec = O.mlp_embedder(W, "time_in", O.timestep_embedding(tt, 256).float()) + O.mlp_embedder(W, "vector_in", y.float())
-        x_txt = O.linear(txt.float(), W["txt_in.weight"], W["txt_in.bias"])
-        pe = O.embed_nd(torch.cat([txt_ids, img_ids], dim=1), OP.axes_dim, OP.theta).to(BF).float()
-        x_img, x_txt = rb(x_img), rb(x_txt)
-        for i in range(OP.depth):
-            x_img, x_txt = O.double_stream_block(W, f"double_blocks.{i}", OP.num_heads, x_img, x_txt, vec, pe)
-            x_img, x_txt = rb(x_img), rb(x_txt)
-        x = torch.cat([x_txt, x_img], dim=1)
-        for i in range(OP.depth_single_blocks):
-            x = rb(O.single_stream_block(W, f"single_blocks.{i}", OP.num_heads, x, vec, pe))
-        out = O.last_layer(W, x[:, x_txt.shape[1]:], vec)
-    e = rel_l2(out, schnell["ref0"])
-    print(f"[d] fp32 oracle with only the residual stream rounded to bf16 between blocks vs plain fp32: {e:.3e}")
-    RESULTS["c2_fp32_oracle_stream_rounded_vs_fp32"] = e
-    _save()
-    assert 1e-3 < e < 2e-2
+# ---------------------------------------------------------------------------------------------------------------------
+# Stored oracle outputs (round 5): the full-size configurations whose oracle forward takes minutes of host time are compared
+# with vectors the oracle produced ONCE on a GPU box (tools/make_full_size_golden.py -> tests/golden/full_size/*.pt; inputs and
+# weights are regenerated from their seeds, and the weights' fingerprint must match the fixture's).  No test in this file is
+# skipped any more: the two env-gated live-oracle runs of round 4 live in that tool (`c3`, `rounding`).
+# Bounds = 1.5 x the error measured when the fixture was generated (recorded inside the fixture as `measured`).
+import full_size_cases as FC      # noqa: E402
 
 
-@pytest.mark.skipif(os.environ.get("FLUXHIP_FULL_ORACLE") != "1", reason="FLUXHIP_FULL_ORACLE=1: ~10 min of host time")
-def test_c3_full_depth_dev_1024_forward(dev):
-    """d: Flux-dev at BASELINE.json configs[2]'s shape (S = 512, L = 4096, T = 4608, guidance 7), one forward."""
-    from flux_generator_amd.flux.model import Flux
-    from flux_generator_amd.flux.utils import configs
-    P = configs["flux-dev"].params
-    flow = Flux(P, device=dev).init_random(4)
-    OP = O.FluxParams(**{k: getattr(P, k) for k in O.FluxParams.__dataclass_fields__})
-    inputs = _inputs(P, 512, 128, seed=2)
-    ts = O.timesteps("flux-dev", 28, 4096)
-    d = [a.to(dev) for a in inputs]
-    got = flow(d[0], d[1], d[2], d[3], torch.full((1,), ts[1], dtype=BF, device=dev), d[4],
-               torch.full((1,), 7.0, dtype=BF, device=dev))
-    ref, secs = _oracle_forward(OP, DeviceWeights(flow.parameters()), inputs, ts[1], guidance=7.0)
-    ref16, _ = _oracle_forward(OP, DeviceWeights(flow.parameters(), dtype=BF), inputs, ts[1], guidance=7.0, dtype=BF)
-    e, e16, eh = rel_l2(got, ref), rel_l2(ref16, ref), rel_l2(got, ref16)
-    print(f"[d] Flux-dev T=4608 full-depth forward: HIP vs bf16 oracle {eh:.3e}; HIP vs fp32 {e:.3e}; bf16 oracle vs fp32 {e16:.3e}  ({secs:.0f} s)")
-    RESULTS["c3_dev1024_forward_rel_l2_vs_bf16_oracle"] = eh
+def _check_hash(case, gold, what):
+    assert case["hash"] == gold["weight_hash"], (
+        f"{what}: the regenerated weights do not fingerprint like the ones the stored oracle output was computed with "
+        "(another torch / device Philox stream?): regenerate with tools/make_full_size_golden.py")
+
+
+def test_c3_dev_1024_forward_vs_stored_oracle(dev):
+    """BASELINE.json configs[2]'s shape - Flux-dev, S = 512, L = 4096, T = 4608, guidance 7 - one full-depth forward against
+    the stored fp32 oracle output and the stored output of the oracle in the reference's own (bf16) arithmetic
+    (flux/model.py:99-136)."""
+    gold = FC.load_golden("c3_dev_t4608.pt")
+    case = FC.c3_case(dev)
+    _check_hash(case, gold, "c3")
+    got = FC.c3_forward(case, dev)
+    e, eh = rel_l2(got, gold["ref_fp32"].float()), rel_l2(got, gold["ref_bf16"].float())
+    m = gold["measured"]
+    print(f"[c3] Flux-dev T=4608: HIP vs stored fp32 oracle {e:.3e} (at generation {m['hip_vs_fp32']:.3e}); vs stored bf16 oracle "
+          f"{eh:.3e} ({m['hip_vs_bf16_oracle']:.3e}); bf16 oracle vs fp32 {m['bf16_oracle_vs_fp32']:.3e}")
     RESULTS["c3_dev1024_forward_rel_l2_vs_fp32"] = e
-    RESULTS["c3_dev1024_bf16_oracle_vs_fp32"] = e16
+    RESULTS["c3_dev1024_forward_rel_l2_vs_bf16_oracle"] = eh
+    RESULTS["c3_dev1024_bf16_oracle_vs_fp32"] = m["bf16_oracle_vs_fp32"]
     _save()
-    assert eh <= 1e-2
-    assert e <= 1.1 * e16 + 5e-4 and e <= 2e-2
+    assert eh <= C3_BOUND_VS_BF16
+    assert e <= 1.1 * m["bf16_oracle_vs_fp32"] + 5e-4 and e <= C3_BOUND_VS_FP32
+
+
+def test_c5_fp8_b4_forward_vs_stored_oracle(dev):
+    """BASELINE.json configs[4] at its per-GPU shape - Flux-schnell, fp8 plan (block-scaled hand-off), B = 4 DISTINCT
+    images, T = 4352 - against the stored fp32 oracle output on the de-quantised weights (txt2image.py:79-82): an oracle
+    bound for the batch-4 launch plan itself, where round 4 compared it with the bf16 HIP forward."""
+    gold = FC.load_golden("c5_fp8_b4_t4352.pt")
+    case = FC.c5_case(dev)
+    _check_hash(case, gold, "c5")
+    got = FC.c5_forward(case, dev)
+    ref = gold["ref_fp32"].float()
+    e = rel_l2(got, ref)
+    per = [rel_l2(got[i], ref[i]) for i in range(4)]
+    m = gold["measured"]
+    print(f"[c5] fp8 B=4 T=4352 vs stored fp32 oracle on de-quantised weights: {e:.3e} (at generation {m['fp8_vs_dequant_fp32']:.3e}); "
+          f"per image {[f'{v:.3e}' for v in per]}; the bf16 plan on the same weights was {m['bf16_plan_vs_dequant_fp32']:.3e}")
+    RESULTS["c5_fp8_b4_forward_rel_l2_vs_dequant_fp32"] = e
+    _save()
+    assert bool(torch.isfinite(got).all())
+    assert e <= C5_BOUND and max(per) <= C5_BOUND
+
+
+def test_c4_sdxl_b16_vs_stored_oracle(dev):
+    """BASELINE.json configs[3] at its batch: the full-size SDXL UNet in float16 on 16 DISTINCT latents / text states; images
+    0 and 11 of the batch against the stored fp32 oracle outputs (stable_diffusion/stable_diffusion/unet.py:403-460)."""
+    gold = FC.load_golden("c4_sdxl_b16.pt")
+    case = FC.c4_case(dev)
+    _check_hash(case, gold, "c4")
+    got = FC.c4_forward(case, dev)
+    assert got.shape == (16, 64, 64, 4) and bool(torch.isfinite(got).all())
+    for i, ref in gold["ref_fp32"].items():
+        e = rel_l2(got[i:i + 1], ref)
+        print(f"[c4] SDXL UNet float16 B=16, image {i} vs stored fp32 oracle: {e:.3e} (at generation {gold['measured']['per_image'][str(i)]:.3e})")
+        RESULTS[f"c4_sdxl_b16_image{i}_rel_l2_vs_fp32"] = e
+        assert e <= C4_BOUND
+    _save()

@@ -358,7 +358,9 @@ def _tiny_sd_zoo(monkeypatch, xl):
 @pytest.mark.parametrize("xl", [True, False])
 def test_pipeline_float16_is_float16_end_to_end(dev, monkeypatch, xl):
     """StableDiffusion[XL](float16=True): UNet, text towers, latents and sampler all float16 (nothing silently bf16), graph ==
-    eager bit for bit, images finite; float16=False keeps bfloat16 storage."""
+    eager bit for bit, images finite.  float16=False is the reference's FLOAT32 arithmetic (stable_diffusion/__init__.py:18-23),
+    which is not built: the constructor says so instead of computing in something narrower; bfloat16 storage is an explicit,
+    named opt-in (storage="bfloat16")."""
     import warnings
     from flux_generator_amd.stable_diffusion import StableDiffusion, StableDiffusionXL
     key = _tiny_sd_zoo(monkeypatch, xl)
@@ -367,7 +369,13 @@ def test_pipeline_float16_is_float16_end_to_end(dev, monkeypatch, xl):
         warnings.simplefilter("ignore")
         sd = cls(key, float16=True)
         sd_eager = cls(key, float16=True, use_graph=False)
-        sd_bf = cls(key, float16=False)
+        sd_bf = cls(key, float16=False, storage="bfloat16")
+    with pytest.raises(NotImplementedError, match="float32"):
+        cls(key, float16=False)
+    with pytest.raises(NotImplementedError, match="float32"):
+        cls(key)                                              # the reference's default constructor
+    with pytest.raises(ValueError):
+        cls(key, float16=True, storage="bfloat16")
     assert sd.dtype == HF and sd_bf.dtype == BF and sd.sampler.coef_dtype == HF and sd_bf.sampler.coef_dtype == torch.float32
     assert all(t.dtype == HF for t in sd.unet.parameters().values())
     assert all(t.dtype == BF for t in sd_bf.unet.parameters().values())
