@@ -75,8 +75,21 @@ DEVINL float gelu_tanh_f(float x) {
   const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, c1, c0));
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-// exact (erf) GELU, used by the SD UNet GEGLU
-DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+// exact (erf) GELU, used by the SD UNet GEGLU and the OpenCLIP towers: x * Phi(x), Phi(x) = 1 - erfc(|x| / sqrt 2) / 2 for x >= 0 and
+// erfc(|x| / sqrt 2) / 2 below (no 1 + erf cancellation on the negative side).  erfc(z) = t (a1 + t (a2 + ... a5 t)) exp(-z^2),
+// t = 1 / (1 + p z) (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute): 14 VALU instructions incl. one v_rcp_f32 and one
+// v_exp_f32 where libm's erff is ~40 with branches - the GEGLU epilogue of the SDXL UNet is 64 gate elements per lane per tile.
+// The result is rounded to float16 / bfloat16 by the caller (>= 2^-11 relative): the approximation is an order below that.
+DEVINL float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.7071067811865476f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float q = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  q = __builtin_fmaf(t, q, 1.421413741f);
+  q = __builtin_fmaf(t, q, -0.284496736f);
+  q = __builtin_fmaf(t, q, 0.254829592f);
+  const float h = 0.5f * (t * q) * __builtin_amdgcn_exp2f(-1.4426950408889634f * (z * z));     // erfc(z) / 2
+  return x * (x >= 0.f ? 1.0f - h : h);
+}
 
 DEVINL float wave_sum(float v) {
 #pragma unroll

@@ -2,6 +2,7 @@
 #include "../../include/fluxhip.h"
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include "gemm_core.h"
 #include "gemm_tiles.h"
 
@@ -336,7 +337,10 @@ hipStream_t g_ws_stream = nullptr;
 bool g_ws_stream_set = false;
 hipEvent_t g_ws_event = nullptr;
 
+std::mutex g_ws_mutex;      // the remembered stream / event are process-global: two host threads launching split-K GEMMs
+                            // (ctypes releases the GIL during a call) must not interleave inside this function
 int serialize_workspace_user(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
   if (g_ws_stream_set && g_ws_stream == s) return FLUXHIP_OK;
   if (g_ws_stream_set) {
     hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;

@@ -198,8 +198,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         float y0 = fmaf(w[u][2 * e], fa[2 * e], fc[2 * e]);
         float y1 = fmaf(w[u][2 * e + 1], fa[2 * e + 1], fc[2 * e + 1]);
         if (silu) {
-          y0 = SPLIT ? y0 / (1.0f + expf(-y0)) : silu_f(y0);       // fp32-faithful path: full-precision exp
-          y1 = SPLIT ? y1 / (1.0f + expf(-y1)) : silu_f(y1);
+          // (round 5: the fp32-faithful path shares the exp2 / rcp form: libm's expf + an IEEE division were ~25 VALU
+          //  instructions per element against 5 - the apply pass is 8 values per lane per 32 bytes moved and was VALU-bound, not
+          //  HBM-bound.  v_exp_f32 / v_rcp_f32 are 1 ulp each, |y| log2(e) rounds once more: <= 1e-6 relative for |y| <= 16, an
+          //  order of magnitude inside the 2^-16 the dropped lo x lo products already cost the convolutions around it.)
+          y0 = silu_f(y0);
+          y1 = silu_f(y1);
         }
         o[e] = e_pack<H>(y0, y1);
         if constexpr (SPLIT) ol[e] = pack_bf16x2(y0 - bf_lo(o[e]), y1 - bf_hi(o[e]));

@@ -47,15 +47,16 @@ def _bf16c(t: torch.Tensor, name: str) -> torch.Tensor:
 F16 = torch.float16
 
 
-def _e16(*named) -> bool:
+def _e16(*named, strided: bool = False) -> bool:
     """Operands of an operator that exists for both 16-bit storage types (bfloat16, and IEEE float16 for the
     stable_diffusion/ models with float16=True): all given (tensor, name) pairs must be contiguous and of ONE of the two
-    types.  Returns True for float16 (-> the `_f16` entry point of include/fluxhip.h)."""
+    types.  Returns True for float16 (-> the `_f16` entry point of include/fluxhip.h).  strided=True: the operator addresses
+    its operands through explicit strides (views into fused projections), so only the element type is checked."""
     dt = None
     for i, (t, name) in enumerate(named):
         if t is None:
             continue
-        if t.dtype not in (BF16, F16) or (i < 2 and not t.is_contiguous()):      # (the first two are the streamed operands)
+        if t.dtype not in (BF16, F16) or (i < 2 and not strided and not t.is_contiguous()):      # (the first two are the streamed operands)
             raise FluxHipError(f"{name} must be a contiguous bfloat16 or float16 tensor")
         if dt is None:
             dt = t.dtype
@@ -672,8 +673,20 @@ def pixel_linear_x3(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor],
 def attention_strided(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, hd: int,
                       Tq: int, Tk: int, Tkpad: int, q_strides, k_strides, ldo: int, scale: float) -> None:
     """q/k addressed as base + b*bs + h*hs + t*rs (element strides); vt [B][H*hd][Tkpad]."""
-    fn, name = _fn("fluxhip_attention_strided_bf16", q.dtype == F16)
+    f16 = _e16((q, "q"), (k, "k"), (vt, "vt"), (out, "out"), strided=True)     # one 16-bit type for all four: no silent reinterpretation
+    fn, name = _fn("fluxhip_attention_strided_bf16", f16)
     _check(fn(_p(q), *q_strides, _p(k), *k_strides, _p(vt), _p(out), ldo, B, H, hd, Tq, Tk, Tkpad, float(scale), _stream()), name)
+
+
+def attention_strided_vt(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, hd: int,
+                         Tq: int, Tk: int, Tkpad: int, q_strides, k_strides, vt_bstride: int, ldo: int, scale: float,
+                         k_off: int = 0, vt_off: int = 0) -> None:
+    """attention_strided with an explicit V^T batch stride; k_off / vt_off = element offsets into k / vt (the UNet's cross-
+    attention layers read their slice of ONE projected text image, stable_diffusion/unet.py `text_kv`)."""
+    f16 = _e16((q, "q"), (k, "k"), (vt, "vt"), (out, "out"), strided=True)
+    fn, name = _fn("fluxhip_attention_strided_vt_bf16", f16)
+    _check(fn(_p(q), *q_strides, _p(k) + k_off * 2, *k_strides, _p(vt) + vt_off * 2, vt_bstride, _p(out), ldo, B, H, hd, Tq, Tk,
+              Tkpad, float(scale), _stream()), name)
 
 
 def layernorm_affine(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
@@ -744,7 +757,8 @@ def sincos_embed(x: torch.Tensor, sig: torch.Tensor, dtype=BF16) -> torch.Tensor
 # ------------------------------------------------------------------------------------------------ text encoders
 def attention_masked(q, k, vt, out, B: int, H: int, Tq: int, Tk: int, Tkpad: int, q_strides, k_strides, ldo: int,
                      scale: float, bias: Optional[torch.Tensor] = None, causal: bool = False) -> None:
-    fn, name = _fn("fluxhip_attention_masked_bf16", q.dtype == F16)
+    f16 = _e16((q, "q"), (k, "k"), (vt, "vt"), (out, "out"), (bias, "bias"), strided=True)
+    fn, name = _fn("fluxhip_attention_masked_bf16", f16)
     _check(fn(_p(q), *q_strides, _p(k), *k_strides, _p(vt), _p(out), ldo, B, H, Tq, Tk, Tkpad, float(scale), _p(bias),
               int(causal), _stream()), name)
 

@@ -289,20 +289,15 @@ class UNetModel:
             ops.gemm(make_gemm_desc([dict(A=W[f"{p}.value_proj.weight"].data_ptr(), W=n.data_ptr(), C=vt.data_ptr(),
                                           a_bstride=0, w_bstride=N * C, c_bstride=C * Tkpad, M=C)],
                                     B, N, C, C, Tkpad), f16)
-            rc = (lib.fluxhip_attention_strided_f16 if f16 else lib.fluxhip_attention_strided_bf16)(qk.data_ptr(), N * 2 * C, 64, 2 * C, qk[..., C:].data_ptr(), N * 2 * C, 64, 2 * C,
-                                                    vt.data_ptr(), o.data_ptr(), C, B, H, 64, N, Tk, Tkpad, 64 ** -0.5,
-                                                    torch.cuda.current_stream().cuda_stream)
+            ops.attention_strided(qk, qk[..., C:], vt, o, B, H, 64, N, Tk, Tkpad, (N * 2 * C, 64, 2 * C), (N * 2 * C, 64, 2 * C), C,
+                                  64 ** -0.5)
         else:
             q = ops.linear(n, W[f"{p}.query_proj.weight"])                    # [B,N,C]
             key, off = self._kv_slot[p]
             k_all, vt_all = kv[key]
             LC, Tkp, Tkpad = k_all.shape[2], kv["Tkp"], kv["Tkpad"]
-            rc = (lib.fluxhip_attention_strided_vt_f16 if f16 else lib.fluxhip_attention_strided_vt_bf16)(q.data_ptr(), N * C, 64, C, k_all.data_ptr() + off * 2, Tkp * LC, 64, LC,
-                                                       vt_all.data_ptr() + off * Tkpad * 2, LC * Tkpad, o.data_ptr(), C,
-                                                       B, H, 64, N, Tk, Tkpad, 64 ** -0.5,
-                                                       torch.cuda.current_stream().cuda_stream)
-        if rc:
-            raise FluxHipError(f"fluxhip_attention_strided failed with code {rc}")
+            ops.attention_strided_vt(q, k_all, vt_all, o, B, H, 64, N, Tk, Tkpad, (N * C, 64, C), (Tkp * LC, 64, LC), LC * Tkpad, C,
+                                     64 ** -0.5, k_off=off, vt_off=off * Tkpad)
         return ops.linear(o, W[f"{p}.out_proj.weight"], W[f"{p}.out_proj.bias"], epi=EPI_GATE_RES, res=y)
 
     def _transformer(self, p: str, H: int, layers: int, x: torch.Tensor, mem: dict, Tk: int) -> torch.Tensor:

@@ -48,7 +48,7 @@ pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 RESULTS = {}
 # bounds of the stored-oracle tests: 1.5 x the error measured when the fixtures were generated (see each fixture's `measured`)
-C3_BOUND_VS_BF16, C3_BOUND_VS_FP32, C5_BOUND, C4_BOUND = 1e-2, 2e-2, 2.5e-2, 2e-3
+C3_BOUND_VS_BF16, C3_BOUND_VS_FP32, C5_BOUND, C4_BOUND = 8.6e-3, 2e-2, 2.3e-2, 1.3e-3      # measured 5.74e-3, 1.426e-2, 1.54e-2 (worst image 1.55e-2), 8.6e-4
 
 
 class DeviceWeights(Mapping):

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Where a NON-split launch of the 256 x 192 ping-pong tile spends its time (GPU box): the phase-stamped generic kernel (cfg 56,
+S = 1) on the Flux K = 3072 shapes - address setup, main loop, barrier after the loop (wave skew), epilogue phase A (bias, bf16,
+LDS writes) and phase B (LDS reads, fused math, 128-byte stores) - per wave, in microseconds at the wave's own measured clock, with
+the spread over the launch's waves (min / mean / max of the whole-wave time: the launch ends with its slowest wave).
+usage: gemm_phase_trace2.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from flux_generator_amd import ops, _lib
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+CASES = {"qkv 1280x9216x3072 bias": (1280, 9216, 3072, ops.EPI_BIAS), "mlp0 1280x12288x3072 gelu": (1280, 12288, 3072, ops.EPI_GELU_TANH),
+         "linear1-sized 1280x21504x3072 bias (2 rounds of this tile: 560 tiles)": (1280, 21504, 3072, ops.EPI_BIAS),
+         "K=12288 1280x9216x12288 bias": (1280, 9216, 12288, ops.EPI_BIAS)}
+for name, (M, N, K, epi) in CASES.items():
+    x = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+    ws = [(torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(4)]
+    b = torch.randn(N, generator=g, device=dev).to(torch.bfloat16)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    trace = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device=dev)
+    for i in range(3):
+        ops.linear(x, ws[i], b, out=out, epi=epi, tile_cfg=56)
+    lib.fluxhip_gemm_set_trace(trace.data_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.linear(x, ws[3], b, out=out, epi=epi, tile_cfg=56)
+    e1.record()
+    torch.cuda.synchronize()
+    lib.fluxhip_gemm_set_trace(None)
+    t = trace.view(-1, 16).cpu().double()
+    t = t[t[:, 8] > 0]
+    ghz = float((t[:, 8] / t[:, 9]).mean()) * 0.1
+    us = lambda c: float(c.mean()) / ghz / 1e3     # noqa: E731
+    whole, setup, epi_all, epa, epb, skew = t[:, 8], t[:, 10], t[:, 11], t[:, 12], t[:, 13], t[:, 14]
+    wus = t[:, 9] / 100.0                           # whole wave by the 100 MHz real-time clock
+    nk = K // 64
+    main = whole - setup - epi_all
+    print(f"{name}: launch (events) {e0.elapsed_time(e1) * 1e3:.1f} us; {len(t)} waves at {ghz:.2f} GHz; whole wave min / mean / max "
+          f"{float(wus.min()):.1f} / {float(wus.mean()):.1f} / {float(wus.max()):.1f} us = setup {us(setup):.1f} + main loop {us(main):.1f} "
+          f"({us(main) / nk:.3f} us per K-step incl. the cold start) + post-loop barrier {us(skew):.1f} + epilogue A {us(epa - skew):.1f} + "
+          f"B {us(epb):.1f} + store drain {us(epi_all - epa - epb):.1f}", flush=True)
