@@ -642,6 +642,25 @@ void gemm_nt_kernel(const GemmParams p) {
           read_frags(a1, w1, slot_a, slot_w, 1);
         }
       };
+      // Interleaved memory phase (round 5, dense bf16 / f16 operands): the phase trace of the loop (tools/gemm_phase_trace2.py) shows
+      // the memory phase of group 0 - 20 fragment reads, then 8 LDS-DMA pieces - taking ~960 cycles against the ~800 of the MFMA
+      // phase it runs beside: the four waves of a group leave the barrier together, so all of them queue at the LDS for their
+      // reads and THEN all of them queue at the CU's one texture-address path for their pieces (16 cycles per piece x 4 waves).
+      // Issued alternately - a few reads, one piece - the LDS serves one wave's reads while another wave's piece holds the
+      // address path.  read_flat(r): fragment read number r of the 2 (MI + NJ) of a K-step, compile-time indexed.
+      // Measured (same box, interleaved runs, profiles/r05_pp_interleave_ab.json): group 0's phase 1148 -> 1134 cycles, group 1's
+      // 864 -> 826, denoise step 17.43 -> 17.29 ms - the reads and the pieces mostly serialise on the LDS port anyway (a K-step
+      // of this tile is 56 pieces x 16 + 160 reads x 4 = 1536 LDS cycles, as many as its MFMAs take), so the gain is small.
+      constexpr bool ILV = !X3 && !F8 && AMODE == 0;
+      constexpr int NRD2 = 2 * (MI + NJ);
+      auto read_flat = [&](auto R, int slot_a, int slot_w, bf16x8(&a0)[MI], bf16x8(&w0)[NJ], bf16x8(&a1)[MI], bf16x8(&w1)[NJ]) {
+        constexpr int r = decltype(R)::value, kk = r / (MI + NJ), q = r % (MI + NJ);
+        const uint32_t aa = a_rd + slot_a * A_BYTES + foff[kk], bb = b_rd + slot_w * B_BYTES + foff[kk];
+        if constexpr (kk == 0 && q < MI) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a0[q]) : "v"(aa), "n"(q * 2048) : "memory");
+        else if constexpr (kk == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w0[q - MI]) : "v"(bb), "n"((q - MI) * 2048) : "memory");
+        else if constexpr (q < MI) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a1[q]) : "v"(aa), "n"(q * 2048) : "memory");
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w1[q - MI]) : "v"(bb), "n"((q - MI) * 2048) : "memory");
+      };
       // FLAG_MXA: the block scales of this wave's 64 rows for one K-step are one dword per lane (byte i = fragment i), fetched
       // a step ahead by an untracked (inline-asm) global load that the loops' own vmcnt waits cover: issued BEFORE the LDS-DMA
       // pieces of the same phase, so every counted wait that lands those pieces lands it too.  sc_cur feeds the MFMAs of the
@@ -826,12 +845,33 @@ void gemm_nt_kernel(const GemmParams p) {
         for (int kt = 0; kt < nkt; ++kt) {
           const int sa1 = REUSE_HI ? (pk == 1) : sa ^ 1, sw1 = sw == 2 ? 0 : sw + 1;   // REUSE_HI: step kt + 1 is a pass 2 iff this is a pass 1
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          GEMM_STAMP(0)                            // (FLAG_TIMED) memory phase of the previous step: reads + A pieces issued, B2, fragments landed
           __builtin_amdgcn_sched_barrier(0);
           mma_both();
           __builtin_amdgcn_sched_barrier(0);
+          GEMM_STAMP(1)                            // 2 x MI x NJ MFMAs issued
           wait_vmcnt<0>();                         // my A(kt+1) pieces (issued one phase ago)
+          GEMM_STAMP(2)
           __builtin_amdgcn_s_barrier();            // B1
+          GEMM_STAMP(3)                            // wait at B1 (for group 1's memory phase)
           // (past the last step this re-reads a valid slot into registers nobody uses: keeps the body branch-free)
+          if constexpr (ILV) {
+            if (kt + 2 < nkt) {
+              long long a_adj, w_adj_unused;
+              const int ks = kstep(kt + 2, a_adj, w_adj_unused);
+              const char* const src0 = abase + ((long long)ks * (BK * 2) + a_adj);
+              static_for<0, PA>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                static_for<i * NRD2 / PA, (i + 1) * NRD2 / PA>([&](auto R) { read_flat(R, sa1, sw1, a0, w0, a1, w1); });
+                uint32_t so = soff[i];
+                asm volatile("" : "+v"(so));
+                glds16(src0 + (size_t)so, smem + sa * A_BYTES + (lw + i * LW) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+              });
+            } else {
+              read_both(sa1, sw1);
+            }
+          } else {
           read_both(sa1, sw1);
           if constexpr (REUSE_HI) {
             // pass 0: slot 0 is read again by step kt + 1, nothing to stage; pass 1: slot 0 has had its last reader
@@ -841,6 +881,7 @@ void gemm_nt_kernel(const GemmParams p) {
             pk = pk == 2 ? 0 : pk + 1;
           } else {
             if (kt + 2 < nkt) stage(kt + 2, sa);
+          }
           }
           __builtin_amdgcn_s_barrier();            // B2
           sa = sa1;
@@ -888,6 +929,25 @@ void gemm_nt_kernel(const GemmParams p) {
         for (int kt = 0; kt < nkt; ++kt) {
           const int sw1 = sw == 2 ? 0 : sw + 1, sw2 = sw1 == 2 ? 0 : sw1 + 1;
           if constexpr (X3) sa = pk == 2;
+          if constexpr (ILV) {
+            if (kt + 2 < nkt) {
+              long long a_adj_unused, w_adj;
+              const int ks = kstep(kt + 2, a_adj_unused, w_adj);
+              const char* const src0 = wbase + ((long long)ks * (BK * 2) + w_adj);
+              static_for<0, PB>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                static_for<i * NRD2 / PB, (i + 1) * NRD2 / PB>([&](auto R) { read_flat(R, sa, sw, a0, w0, a1, w1); });
+                uint32_t wo = woff[i];
+                asm volatile("" : "+v"(wo));
+                glds16(src0 + (size_t)wo, smem + W_BASE + sw2 * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+              });
+              wait_vmcnt<PB>();
+            } else {
+              read_both(sa, sw);
+              wait_vmcnt<0>();
+            }
+          } else {
           read_both(sa, sw);
           if constexpr (MXA) { if (kt + 1 < nkt) mx_load(sc_nxt); }   // scales of step kt + 1, ahead of W(kt + 2): the wait below lands them
           if (kt + 2 < nkt) {
@@ -896,12 +956,17 @@ void gemm_nt_kernel(const GemmParams p) {
           } else {
             wait_vmcnt<0>();
           }
+          }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slot kt are done before it is refilled
+          GEMM_STAMP(4)                            // (FLAG_TIMED) memory phase: reads + W pieces issued, W(kt+1) landed, fragments landed
           __builtin_amdgcn_s_barrier();            // B1
+          GEMM_STAMP(5)                            // wait at B1 (for group 0's MFMA phase)
           __builtin_amdgcn_sched_barrier(0);
           mma_both();
           __builtin_amdgcn_sched_barrier(0);
+          GEMM_STAMP(6)                            // MFMAs issued
           __builtin_amdgcn_s_barrier();            // B2
+          GEMM_STAMP(7)                            // wait at B2 (for group 0's memory phase)
           if constexpr (MXA) {
             asm volatile("" : "+v"(sc_nxt));
             sc_cur = sc_nxt;

@@ -43,3 +43,12 @@ for name, (M, N, K, epi) in CASES.items():
           f"{float(wus.min()):.1f} / {float(wus.mean()):.1f} / {float(wus.max()):.1f} us = setup {us(setup):.1f} + main loop {us(main):.1f} "
           f"({us(main) / nk:.3f} us per K-step incl. the cold start) + post-loop barrier {us(skew):.1f} + epilogue A {us(epa - skew):.1f} + "
           f"B {us(epb):.1f} + store drain {us(epi_all - epa - epb):.1f}", flush=True)
+    # per-phase stamps of the ping-pong loop (shader cycles per K-step): waves 0-3 of a block = group 0 (stages A), 4-7 = group 1
+    wave = torch.arange(len(t)) % 8
+    g0, g1 = t[wave < 4], t[wave >= 4]
+    cyc = lambda c: float(c.mean()) / nk       # noqa: E731
+    print(f"    group 0 per K-step [cycles]: MFMAs issued {cyc(g0[:, 1]):.0f} | wait A(kt+1) {cyc(g0[:, 2]):.0f} | B1 wait {cyc(g0[:, 3]):.0f} | "
+          f"reads + A pieces issued, B2, fragments landed {cyc(g0[:, 0]):.0f}   (sum {cyc(g0[:, 0] + g0[:, 1] + g0[:, 2] + g0[:, 3]):.0f})")
+    print(f"    group 1 per K-step [cycles]: reads + W pieces issued, W(kt+1) + fragments landed {cyc(g1[:, 4]):.0f} | B1 wait {cyc(g1[:, 5]):.0f} | "
+          f"MFMAs issued {cyc(g1[:, 6]):.0f} | B2 wait {cyc(g1[:, 7]):.0f}   (sum {cyc(g1[:, 4] + g1[:, 5] + g1[:, 6] + g1[:, 7]):.0f}); "
+          f"2 x MI x NJ x 16 = {2 * 4 * 6 * 16} MFMA cycles per group and K-step", flush=True)
