@@ -5,7 +5,7 @@ Tolerances:
   * the row quantiser is BIT-EXACT against torch's float8_e4m3fn round-to-nearest-even conversion of x / scale;
   * fluxhip_gemm_fp8 vs a float64 product of the DEQUANTISED operands: rel-L2 <= 4e-3 (fp32 accumulation, bf16 output
     rounding — the quantisation itself is outside this comparison, so the kernel is checked exactly);
-  * a whole tiny Flux forward in fp8 vs the fp32 oracle evaluated with the DE-QUANTISED weights: rel-L2 <= 6e-2 — the
+  * a whole tiny Flux forward in fp8 vs the fp32 oracle evaluated with the DE-QUANTISED weights: rel-L2 <= 1e-2 (measured 6.5e-3) — the
     remaining difference is the per-token e4m3 rounding of the activations (3 mantissa bits, ~2^-4 relative per
     element, averaging down over each 256..1280-term dot product) accumulated over the blocks.
 """
@@ -118,7 +118,7 @@ def test_flux_forward_fp8(dev, B, S, hw):
     ref = O.flux_forward(OP, Wd, img.float(), ids, txt.float(), tids, t, vec.float())
     e, e16 = rel_l2(got, ref), rel_l2(got, bf16_out.float().cpu())
     print(f"fp8 tiny forward: rel-L2 vs oracle(dequantised weights) {e:.2e}; vs the bf16 HIP forward {e16:.2e}")
-    assert e < 6e-2
+    assert e < 1e-2                       # measured 6.3e-3 / 6.5e-3 (1.5 x)
     # the block-scaled hand-off (GELU epilogue -> e4m3 + E8M0 block scales -> next Linear) is taken when every stream is whole
     # 64-row groups; the per-token plan with its stand-alone quantise passes stays within the same budget of the oracle
     ws = next(iter(model._ws.values()))
@@ -133,7 +133,7 @@ def test_flux_forward_fp8(dev, B, S, hw):
         model.fp8_mx = True
         e_pt = rel_l2(per_token, ref)
         print(f"   per-token plan vs oracle {e_pt:.2e}; block-scaled vs per-token plan {rel_l2(got, per_token.float().cpu()):.2e}")
-        assert e_pt < 6e-2 and e < 1.25 * e_pt + 5e-3
+        assert e_pt < 1e-2 and e < 1.25 * e_pt + 2e-3
     model.enable_fp8(False)
     assert torch.equal(model(*args), bf16_out)                    # switching back restores the bf16 plan exactly
 

@@ -9,6 +9,7 @@ from oracle import flux_oracle as O
 from oracle import text_oracle as T
 
 pytestmark = pytest.mark.gpu
+CLIP_FP8_BOUND = 6e-2      # (tightened to 1.5 x measured once printed by a GPU run; see test_text_towers_fp8)
 BF = torch.bfloat16
 
 
@@ -184,7 +185,7 @@ def test_clip_l_real_width_full_depth(dev):
 def test_text_towers_fp8_quantize(dev):
     """`--quantize` on the text towers (txt2image.py:79-82): T5 with e4m3 Linears (per-channel weights, per-token inputs; the
     value projection stays bf16) against the text oracle on the DE-QUANTISED weights, and CLIP with its second MLP Linear
-    quantised (the only one passing the reference's in_dim % 512 predicate).  Bound as for the flow model's fp8 path: 6e-2."""
+    quantised (the only one passing the reference's in_dim % 512 predicate).  Bounds: 1.5 x the measured errors (T5 2.38e-2; CLIP: CLIP_FP8_BOUND)."""
     from flux_generator_amd import ops
     from flux_generator_amd.flux.clip import CLIPTextModel, CLIPTextModelConfig
     from flux_generator_amd.flux.t5 import T5Config, T5Encoder
@@ -215,7 +216,7 @@ def test_text_towers_fp8_quantize(dev):
     ref = T.t5_encoder(ocfg, Wd, tokens)
     e = rel_l2(got, ref)
     print(f"t5 fp8 vs oracle on de-quantised weights: {e:.2e}; vs the bf16 encoder: {rel_l2(got, plain.float().cpu()):.2e}")
-    assert e < 6e-2
+    assert e < 3.6e-2                     # measured 2.38e-2 (1.5 x)
     model.enable_fp8(False)
     assert torch.equal(model(tokens), plain)
 
@@ -233,4 +234,6 @@ def test_text_towers_fp8_quantize(dev):
         q, sc = clip._w8[i]
         Wc[f"layers.{i}.linear2.weight"] = (q.view(torch.float8_e4m3fn).float() * sc.float()[:, None]).cpu()
     refc = T.clip_text_model(ccfg, Wc, toks)
-    assert rel_l2(out.last_hidden_state, refc.last_hidden_state) < 6e-2 and rel_l2(out.pooled_output, refc.pooled_output) < 6e-2
+    e_h, e_p = rel_l2(out.last_hidden_state, refc.last_hidden_state), rel_l2(out.pooled_output, refc.pooled_output)
+    print(f"clip fp8 (second MLP Linear) vs oracle on de-quantised weights: hidden {e_h:.2e}, pooled {e_p:.2e}")
+    assert e_h < CLIP_FP8_BOUND and e_p < CLIP_FP8_BOUND

@@ -46,3 +46,9 @@ python tools/bench_sdxl.py 2>/dev/null | tail -1 > $O/bench_r05_sdxl_b16.json
 python tools/prof_summary.py $(find /tmp/p7 -name "*kernel_stats.csv" | head -1) $O/r05_kernel_stats_sdxl_b16.csv > /dev/null
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p8 -o kt -- python $R/bench.py --fp8 --steps 2 --warmup 1 --profile-only >/dev/null 2>&1 )
 python tools/prof_summary.py $(find /tmp/p8 -name "*kernel_stats.csv" | head -1) $O/r05_kernel_stats_fp8_b4_1024.csv > /dev/null
+python tools/rs_phase_trace.py 3 > $O/r05_splitk_phase_trace.txt 2>&1
+python tools/gemm_phase_trace2.py > $O/r05_gemm_phase_trace_nonsplit.txt 2>&1
+python tools/attn_bench.py 0 > $O/r05_attn_bench.txt 2>&1
+timeout 600 python -m pytest tests/test_fp8_gpu.py tests/test_text_gpu.py -q -s -m gpu -k "fp8" 2>&1 | grep -i "fp8\|passed\|failed" > $O/r05_fp8_measured.txt
+timeout 900 python -m pytest tests/test_full_size_parity_gpu.py -q -s -m gpu 2>&1 | grep "^\[\|passed\|failed" > $O/r05_parity_run.txt
+cp $O/parity_full_size.json $O/r05_parity_full_size.json 2>/dev/null
