@@ -483,6 +483,13 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     g_attr_set[cfg_idx][slot] = true;
   }
   p.trace = g_trace;
+  if (conv) {
+    // buffer-addressed activation loader (ping-pong conv tiles, gemm_core.h ConvGeom::buf): the image, its lo plane and the bias
+    // that keeps lane offsets non-negative must fit the resource's 32-bit num_records with room for the out-of-range marker
+    static const bool buf_off = [] { const char* e = getenv("FLUXHIP_CONV_BUF"); return e && e[0] == '0'; }();
+    const long long bias_b = (2LL * p.cv.Ws + 2) * p.cv.Cin * 2;
+    p.cv.buf = (!buf_off && !p.cv.ups && p.cv.x_extent > 0 && p.cv.x_extent + bias_b + 4096 < 0xFFF00000LL) ? 1 : 0;
+  }
   // LDS-transposed epilogue needs every output-side operand addressable in 16-byte units
   auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   bool wide = !x3 && !p.out_f32 && p.N % 8 == 0 && p.ldc % 8 == 0;
@@ -826,6 +833,7 @@ static int conv2d_16(const void* x, const void* w, const void* bias, const void*
   p.cv.zero = (const bf16_t*)zero16;
   p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Ho; p.cv.Wo = Wo;
   p.cv.Cin = Cin; p.cv.ksize = ksize; p.cv.stride = stride; p.cv.pad = pad; p.cv.ups = ups;
+  p.cv.x_extent = (long long)B * Hs * Ws * Cin * 2;
   GemmGroup& t = p.g[0];
   t.A = (const bf16_t*)x;
   t.W = (const bf16_t*)w;
@@ -882,6 +890,7 @@ extern "C" int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int
   p.cv.zero = (const bf16_t*)zero16;
   p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Ho; p.cv.Wo = Wo;
   p.cv.Cin = Cin; p.cv.ksize = ksize; p.cv.stride = stride; p.cv.pad = pad; p.cv.ups = ups;
+  p.cv.x_extent = x_lo >= 0 ? (x_lo + (long long)B * Hs * Ws * Cin) * 2 : 0;       // hi plane, then the lo plane x_lo elements on
   GemmGroup& t = p.g[0];
   t.A = (const bf16_t*)x;
   t.W = (const bf16_t*)w;
@@ -927,6 +936,7 @@ extern "C" int fluxhip_conv_up2x_x3(const void* x, int64_t x_lo, const void* w4,
   p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Hs; p.cv.Wo = Ws;
   p.cv.Cin = Cin; p.cv.ksize = 2; p.cv.stride = 1; p.cv.pad = 0; p.cv.ups = 0;
   p.cv.sub2 = 1;
+  p.cv.x_extent = x_lo >= 0 ? (x_lo + (long long)B * Hs * Ws * Cin) * 2 : 0;
   GemmGroup& t = p.g[0];
   t.A = (const bf16_t*)x;
   t.W = (const bf16_t*)w4;

@@ -71,6 +71,14 @@ struct ConvGeom {        // implicit-GEMM A loader (NHWC activations)
   // top-left is (y + sdy - 1, x + sdx - 1) and output row m = (img, y, x) is stored at (img, 2y + sdy, 2x + sdx) of
   // the [B][2Ho][2Wo] output.  FLAG_SPLIT kernels only.
   int sub2;
+  // Round 5, ping-pong conv tiles: the activation image addressed through a BUFFER RESOURCE (buffer_load ... lds).  A piece's
+  // source is then (32-bit lane offset, constant over the K loop) + (scalar offset of the step's tap / channel chunk / plane), and
+  // a border tap is a lane offset that fails the resource's range check - the hardware writes zeros - instead of a 64-bit
+  // address rebuilt and selected against a zero page per piece (~10 VALU per piece in the memory phase of group 0, the critical
+  // path of the loop).  x_extent = bytes from X to the end of the last plane the loader may touch (hi [+ lo]); buf = 1 when the
+  // launcher found x_extent + the bias below to fit 32 bits.
+  long long x_extent;
+  int buf;
 };
 
 DEVINL int conv_tap_row(int ksize, int tap) { return ksize == 3 ? tap / 3 : (ksize == 2 ? tap >> 1 : 0); }
@@ -708,6 +716,9 @@ void gemm_nt_kernel(const GemmParams p) {
         const char* const abase = (const char*)gA + (long long)b * a_bs * ESZ;
         int gyx[PA];
         uint32_t gimg[PA];
+        const uint32_t cbias = AMODE == 1 ? (uint32_t)((2 * p.cv.Ws + 2) * p.cv.Cin * 2) : 0u;
+        const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+            AMODE == 1 ? (void*)((const char*)p.cv.X - cbias) : nullptr, 0, AMODE == 1 ? (int)(uint32_t)(p.cv.x_extent + cbias) : 0, 0x00020000);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
           const int row = (lw + i * LW) * 8 + lr;
@@ -733,6 +744,9 @@ void gemm_nt_kernel(const GemmParams p) {
               }
               gyx[i] = mask;
               gimg[i] = (uint32_t)(int)((img + ((long long)y0 * p.cv.Ws + x0) * p.cv.Cin) >> 3);
+              // buffer mode: byte offset from (X - cbias), never negative (the window's top-left is at most two rows and two
+              // pixels before the image), this lane's 16-byte chunk included
+              if (p.cv.buf) gimg[i] = gimg[i] * 16u + (uint32_t)(lc * 16) + cbias;
             }
           }
         }
@@ -755,6 +769,13 @@ void gemm_nt_kernel(const GemmParams p) {
               uint32_t so = soff[i];
               asm volatile("" : "+v"(so));           // opaque: keeps the 64-bit sum out of loop-invariant hoisting
               s_ = abase + ((long long)ks * (BK * 2) + a_adj) + (size_t)so;            // scalar base + 32-bit lane offset
+            } else if (!p.cv.ups && p.cv.buf) {
+              // border taps: an offset beyond num_records -> the LDS-DMA writes zeros (tools/probes/buffer_lds_oob_probe.hip)
+              const uint32_t soffs = (uint32_t)(((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj);    // wave-uniform
+              const uint32_t vo = ((gyx[i] >> tap) & 1) ? gimg[i] : 0xFFFFFFF0u;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + (lw + i * LW) * 1024),
+                                                       16, vo, soffs, 0, 0);
+              continue;
             } else if (!p.cv.ups) {
               const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj;
               // opaque copy: otherwise hipcc hoists the loop-invariant 64-bit cX + img * 16 of every piece out of the
