@@ -19,6 +19,9 @@ FLUXHIP_TILES_X3(X)
 FLUXHIP_TILES_F8(X)
 #undef X
 
+extern template __global__ void gemm_nt_kernel<256, 256, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>(const GemmParams);
+extern template __global__ void gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>(const GemmParams);
+
 // instantiated in gemm_mx.hip
 #define X(BM, BN, WM, WN, NS, PIPE) extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_FP8 | FLAG_LEAN | FLAG_MXA>(const GemmParams);
 FLUXHIP_TILES_MXA(X)
@@ -546,6 +549,12 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     if (serialize_workspace_user(s) != FLUXHIP_OK) return FLUXHIP_ELAUNCH;
     g_rs_launches += p.sk_mode != 0;
     if (p.sk_mode && !use(c.dense_rs, 5)) return FLUXHIP_ELAUNCH;
+  }
+  if (conv && x3 && g_trace && (cfg_idx == 49 || cfg_idx == 52)) {      // diagnostic: the stamped twin of the fp32-faithful conv tile
+    void (*const tk)(const GemmParams) = cfg_idx == 49 ? gemm_nt_kernel<256, 256, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>
+                                                       : gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>;
+    if (hipFuncSetAttribute((const void*)tk, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess) return FLUXHIP_ELAUNCH;
+    fn = tk;
   }
   dim3 grid(tm_total * p.tiles_n * splits), block(c.threads);
   hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);

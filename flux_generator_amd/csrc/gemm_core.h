@@ -762,37 +762,48 @@ void gemm_nt_kernel(const GemmParams p) {
             dy = conv_tap_row(p.cv.ksize, tap);
             dx = tap - dy * p.cv.ksize;
           }
+          // One wave-uniform decision per STAGE, then a straight run of PA pieces.  (As one loop with the loader variants selected
+          // inside it, hipcc kept the selection per piece: ~6 scalar branches around every LDS-DMA instruction, and the phase trace
+          // of the fp32-faithful conv tiles showed this group's memory phase at ~2000 cycles against ~1100 for the dense loader.)
+          if constexpr (AMODE == 0) {
 #pragma unroll
-          for (int i = 0; i < PA; ++i) {
-            const char* s_ = nullptr;
-            if (AMODE == 0) {
+            for (int i = 0; i < PA; ++i) {
               uint32_t so = soff[i];
               asm volatile("" : "+v"(so));           // opaque: keeps the 64-bit sum out of loop-invariant hoisting
-              s_ = abase + ((long long)ks * (BK * 2) + a_adj) + (size_t)so;            // scalar base + 32-bit lane offset
-            } else if (!p.cv.ups && p.cv.buf) {
-              // border taps: an offset beyond num_records -> the LDS-DMA writes zeros (tools/probes/buffer_lds_oob_probe.hip)
-              const uint32_t soffs = (uint32_t)(((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj);    // wave-uniform
+              glds16(abase + ((long long)ks * (BK * 2) + a_adj) + (size_t)so, smem + slot * A_BYTES + (lw + i * LW) * 1024);   // scalar base + 32-bit lane offset
+            }
+          } else if (!p.cv.ups && p.cv.buf) {
+            // border taps: an offset beyond num_records -> the LDS-DMA writes zeros (tools/probes/buffer_lds_oob_probe.hip)
+            const uint32_t soffs = (uint32_t)(((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj);    // wave-uniform
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
               const uint32_t vo = ((gyx[i] >> tap) & 1) ? gimg[i] : 0xFFFFFFF0u;
               __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void*)(smem + slot * A_BYTES + (lw + i * LW) * 1024),
                                                        16, vo, soffs, 0, 0);
-              continue;
-            } else if (!p.cv.ups) {
-              const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj;
+            }
+          } else if (!p.cv.ups) {
+            const long long uoff = ((long long)(dy * p.cv.Ws + dx) * p.cv.Cin + c0) * 2 + a_adj;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
               // opaque copy: otherwise hipcc hoists the loop-invariant 64-bit cX + img * 16 of every piece out of the
               // K loop, spills the 8 pairs to scratch and reloads one per piece per stage - VMEM loads whose vmcnt(0)
               // waits drain the LDS-DMA pieces in flight
               uint32_t img = gimg[i];
               asm volatile("" : "+v"(img));
-              s_ = ((gyx[i] >> tap) & 1) ? cX + (long long)(int)img * 16 + uoff : (const char*)p.cv.zero;
-            } else {
+              const char* s_ = ((gyx[i] >> tap) & 1) ? cX + (long long)(int)img * 16 + uoff : (const char*)p.cv.zero;
+              glds16(s_, smem + slot * A_BYTES + (lw + i * LW) * 1024);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
               const int yy = (gyx[i] >> 16) + dy, xx = (int)(short)(gyx[i] & 0xffff) + dx;
               const bool ok = (yy >= 0) & (yy < p.cv.Hs * 2) & (xx >= 0) & (xx < p.cv.Ws * 2);
               uint32_t img = gimg[i];
               asm volatile("" : "+v"(img));
-              s_ = ok ? cX + (long long)img * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2 + a_adj
-                      : (const char*)p.cv.zero;
+              const char* s_ = ok ? cX + (long long)img * 16 + ((long long)((yy >> 1) * p.cv.Ws + (xx >> 1)) * p.cv.Cin + c0) * 2 + a_adj
+                                  : (const char*)p.cv.zero;
+              glds16(s_, smem + slot * A_BYTES + (lw + i * LW) * 1024);
             }
-            glds16(s_, smem + slot * A_BYTES + (lw + i * LW) * 1024);
           }
         };
         // Only step 0 has to be in LDS before the first MFMA: waiting for step 1 as well made every CU of the
@@ -1157,6 +1168,78 @@ void gemm_nt_kernel(const GemmParams p) {
 #undef GEMM_STAMP
   }
 
+  // ---- operands of the epilogue that depend on nothing the split-K hand-off produces (bias, dequantisation scales, residual and
+  //      gate): declared here so that a reduce-scatter block can request them while it waits for its peers
+  const float alpha = p.alpha;
+  constexpr int LEPI = (FLAGS >> 8) & 15;      // FLAG_LEAN kernels may fix their ONE epilogue at compile time (see the epilogue)
+  const int epi = LEPI ? LEPI - 1 : p.epi;
+  // bias operands are fetched up front (one batch of loads in flight, not one dependent load per MFMA tile): by a reduce-scatter
+  // block right after the drain of its partial stores (a vmcnt(0) that would otherwise wait for these loads as well), by every other
+  // launch where the epilogue starts
+  u32x2 bcol[NJ];
+  float brow[MI];
+  bool bias_loaded = false;
+  auto load_bias = [&]() {
+    const bool colb = gBias && (LEAN || !p.row_bias), rowb = !LEAN && gBias && p.row_bias;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n4 = min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4);
+      bcol[j] = colb ? *(const u32x2*)(gBias + n4) : u32x2{0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) brow[i] = rowb ? e2f<F16>(gBias[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)]) : 0.f;
+    bias_loaded = true;
+  };
+  // FLAG_FP8: dequantisation scales of this lane's rows (activation, per token) and columns (weight, per channel)
+  float asc[F8 ? MI : 1];
+  f32x4 wsc[F8 ? NJ : 1];
+  if constexpr (F8) {
+    const float* as_ = (g1 ? p.a_scale[1] : p.a_scale[0]) + (long long)b * p.a_sc_bstride;
+    const float* ws_ = g1 ? p.w_scale[1] : p.w_scale[0];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) asc[i] = MXA ? alpha : as_[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)] * alpha;   // MXA: the MFMA applied the block scales
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wsc[j] = *(const f32x4*)(ws_ + min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4));
+  }
+  // Gate-residual epilogue (phase B of the LDS-transposed path): item t * 64 + lane of this wave = 8 consecutive columns of one
+  // row of its sub-tile (of the part a reduce-scatter block owns: rows [r_lo, r_lo + nr) x chunks [c_lo, c_lo + ncw)).  gr_load
+  // requests the residual and gate operands of FOUR items per lane before any is used (clamped addresses, no branch around a
+  // load): as one item per trip - LDS read, residual + gate loads, arithmetic, store - the loop was a chain of dependent global
+  // round trips, ~6 us for the third of a tile a reduce-scatter block finishes against 4.3 us for a WHOLE tile of the bias-only
+  // epilogue.  A reduce-scatter block requests its first four items BEFORE the exchange (its ownership is known from its split
+  // index), so their round trip runs under the hand-off; the residual may alias the output: only this block writes these elements.
+  constexpr int NCH_E = WTN / 8;
+  struct GrItems { bool ok[4]; int rowc[4], cc[4]; long long off[4]; u32x4 rv[4], gv[4]; };
+  auto gr_load = [&](GrItems& it, int t0, int nit, bool sub, int r_lo, int nr, int c_lo, int ncw) {
+    const bf16_t* const resb = gRes + (long long)b * c_bs;
+    const bf16_t* const gateb = gGate ? gGate + (long long)b * gate_bs : nullptr;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = (t0 + u) * 64 + lane;
+      int row, c;
+      bool v_ = t0 + u < nit;
+      if (sub) {
+        const int rr = (int)((unsigned)idx / (unsigned)ncw);
+        row = r_lo + rr;
+        c = c_lo + idx - rr * ncw;
+        v_ = v_ && rr < nr;
+      } else {
+        row = idx / NCH_E;
+        c = idx - row * NCH_E;
+      }
+      const int m = m0 + wm * WTM + row, n8 = n0 + wn * WTN + c * 8;
+      v_ = v_ && row < WTM && m < Mg && n8 < N;
+      it.ok[u] = v_;
+      it.rowc[u] = v_ ? row : 0;
+      it.cc[u] = v_ ? c : 0;
+      const int mc = v_ ? m : min(m0, Mg - 1), nc = v_ ? n8 : 0;       // (an item that is switched off reads a valid address and drops the value)
+      it.off[u] = (long long)mc * p.ldc + nc;
+      it.rv[u] = *(const u32x4*)(resb + it.off[u]);
+      it.gv[u] = gateb ? *(const u32x4*)(gateb + nc) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  GrItems gr_pf;
+  bool gr_prefetched = false;
   // ---- split-K hand-off (see the block map above) ---------------------------------------------
   // Owned fragment range of this block: everything unless the reduce-scatter hand-off below narrows it.
   int oi_lo = 0, oi_hi = MI, oj_lo = 0, oj_hi = NJ;
@@ -1214,8 +1297,18 @@ void gemm_nt_kernel(const GemmParams p) {
       __syncthreads();
       int* arrive = p.sk_flag + bid;
       int* const bcast = (int*)smem;                  // the operand ring is dead (block barrier above)
+      int old = 0;
+      if (tid == 0) old = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // Epilogue operands of the part this block owns (bias; residual + gate of its first four items, see gr_load): requested HERE -
+      // after the arrival (the peers are not kept waiting) and behind the block barrier above (a __syncthreads() ahead of them would
+      // wait for them: measured, the whole hand-off moved out by their latency) - so they land while lane 0 polls for the peers.
+      load_bias();
+      if (epi == EPI_GATE_RES) {
+        const int nr_ = (oi_hi - oi_lo) * 16, ncw_ = (oj_hi - oj_lo) * 2;
+        gr_load(gr_pf, 0, (nr_ * ncw_ + 63) >> 6, true, oi_lo * 16, nr_, oj_lo * 2, ncw_);
+        gr_prefetched = true;
+      }
       if (tid == 0) {
-        const int old = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int gave_up = 0, orphans = 0;
         if ((old & 255) + 1 == S) {
           orphans = old >> 8;                           // last arriver: never waits, finishes what was orphaned before it came
@@ -1344,9 +1437,6 @@ void gemm_nt_kernel(const GemmParams p) {
   // The direct path remains for float32 outputs and for operands that are not 16-byte aligned.
   // FLAG_LEAN kernels may also fix their ONE epilogue at compile time (FLAGS bits 8-11 = epilogue code + 1): every
   // `epi ==` below folds and the kernel carries a single store path
-  constexpr int LEPI = (FLAGS >> 8) & 15;
-  const int epi = LEPI ? LEPI - 1 : p.epi;
-  const float alpha = p.alpha;
   if constexpr (X3) {
     // FLAG_SPLIT epilogue: v = alpha * acc + bias (float32 bias, by column or by row) [+ residual (hi + lo planes)],
     // then either float32 out (attention logits) or the hi / lo bf16 planes of v.  Direct stores from the MFMA
@@ -1410,6 +1500,17 @@ void gemm_nt_kernel(const GemmParams p) {
         if (r16 == 0 && n4 < N) *(float2*)(dst + (long long)n4 * 2) = float2{s_, q_};
       }
     }
+    if constexpr ((FLAGS & FLAG_TIMED) != 0) {       // diagnostic fp32-faithful conv tiles (tools/conv_phase_trace.py)
+      unsigned long long t_end, rt_end;
+      asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t_end), "=s"(rt_end)::"memory");
+      if (p.trace && lane == 0) {
+        unsigned long long* t = p.trace + ((long long)blockIdx.x * NWAVES + wave) * 16;
+        t[8] = t_end - t_start;
+        t[9] = rt_end - rt_start;
+        t[10] = t_loop0 - t_start;
+        t[11] = t_end - t_loop1;
+      }
+    }
     return;
   }
   constexpr int NCH = WTN / 8;                      // 16-byte chunks per row of the wave's sub-tile
@@ -1420,30 +1521,7 @@ void gemm_nt_kernel(const GemmParams p) {
   unsigned long long t_epi0 = 0;
   if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_epi0)::"memory");
 
-  // bias operands are fetched up front (one batch of loads in flight, not one dependent load per MFMA tile)
-  u32x2 bcol[NJ];
-  float brow[MI];
-  {
-    const bool colb = gBias && (LEAN || !p.row_bias), rowb = !LEAN && gBias && p.row_bias;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n4 = min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4);
-      bcol[j] = colb ? *(const u32x2*)(gBias + n4) : u32x2{0u, 0u};
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) brow[i] = rowb ? e2f<F16>(gBias[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)]) : 0.f;
-  }
-  // FLAG_FP8: dequantisation scales of this lane's rows (activation, per token) and columns (weight, per channel)
-  float asc[F8 ? MI : 1];
-  f32x4 wsc[F8 ? NJ : 1];
-  if constexpr (F8) {
-    const float* as_ = (g1 ? p.a_scale[1] : p.a_scale[0]) + (long long)b * p.a_sc_bstride;
-    const float* ws_ = g1 ? p.w_scale[1] : p.w_scale[0];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) asc[i] = MXA ? alpha : as_[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)] * alpha;   // MXA: the MFMA applied the block scales
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) wsc[j] = *(const f32x4*)(ws_ + min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4));
-  }
+  if (!bias_loaded) load_bias();
   // (ADDVEC is a compile-time tag so the common path carries no per-tile branch or integer division)
   auto biased = [&](auto addvec_tag, int i, int j, int m, int n4, float (&v)[4]) {
     if constexpr (F8) {
@@ -1574,6 +1652,37 @@ void gemm_nt_kernel(const GemmParams p) {
     // reduce-scatter split-K: the owned rows [r_lo, r_lo + nr) x chunks [c_lo, c_lo + ncw) of the wave's sub-tile only
     const int r_lo = oi_lo * 16, nr = (oi_hi - oi_lo) * 16, c_lo = oj_lo * 2, ncw = (oj_hi - oj_lo) * 2;
     const int nit = rs ? (nr * ncw + 63) >> 6 : NIT;
+    if (!MXC && epi == EPI_GATE_RES) {
+      // gate-residual form: four items per lane and trip, operands requested together (gr_load above the split-K hand-off)
+      const bool gated = gGate != nullptr;
+      for (int t0 = 0; t0 < nit; t0 += 4) {
+        GrItems cur;
+        if (t0 == 0 && gr_prefetched) cur = gr_pf;
+        else gr_load(cur, t0, nit, RS_CAPABLE && rs, r_lo, nr, c_lo, ncw);
+        u32x4 xs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xs[u] = *(const u32x4*)(my_lds + cur.rowc[u] * (NCH * 16) + cswz(cur.cc[u], cur.rowc[u]) * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!cur.ok[u]) continue;
+          u32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x0 = e_lo<F16>(xs[u][r]), x1 = e_hi<F16>(xs[u][r]);
+            float y0, y1;
+            if (gated) {
+              y0 = e_lo<F16>(cur.rv[u][r]) + e_rnd<F16>(e_lo<F16>(cur.gv[u][r]) * x0);
+              y1 = e_hi<F16>(cur.rv[u][r]) + e_rnd<F16>(e_hi<F16>(cur.gv[u][r]) * x1);
+            } else {
+              y0 = e_lo<F16>(cur.rv[u][r]) + x0;
+              y1 = e_hi<F16>(cur.rv[u][r]) + x1;
+            }
+            o[r] = e_pack<F16>(y0, y1);
+          }
+          *(u32x4*)(gC + (long long)b * c_bs + cur.off[u]) = o;
+        }
+      }
+    } else
 #pragma unroll 4
     for (int t = 0; t < nit; ++t) {
       const int idx = t * 64 + lane;

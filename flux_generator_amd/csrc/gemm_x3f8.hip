@@ -11,3 +11,6 @@ FLUXHIP_TILES_X3(X)
 #define X(BM, BN, WM, WN, NS, PIPE) template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_FP8>(const GemmParams);
 FLUXHIP_TILES_F8(X)
 #undef X
+// diagnostic: the two ping-pong fp32-faithful conv tiles with phase stamps (fluxhip_gemm_set_trace; tools/conv_phase_trace.py)
+template __global__ void gemm_nt_kernel<256, 256, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>(const GemmParams);
+template __global__ void gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>(const GemmParams);
