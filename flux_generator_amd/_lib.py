@@ -69,6 +69,8 @@ SIGNATURES = {
     "fluxhip_gemm_tile_cfg": (c_int, [C.POINTER(GemmDesc)]),
     "fluxhip_gemm_tile_shape": (c_int, [c_int, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),
     "fluxhip_gemm_set_trace": (c_int, [c_void_p]),
+    "fluxhip_conv_set_x3_tile": (c_int, [c_int, c_int]),
+    "fluxhip_conv_dxr_launches": (C.c_int64, []),
     "fluxhip_gemm_set_splitk_mode": (c_int, [c_int]),
     "fluxhip_attention_set_variant": (c_int, [c_int]),
     "fluxhip_gemm_rs_launches": (C.c_int64, []),
@@ -182,7 +184,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fluxhip_abi_version() != 7 and not ab:
+    if lib.fluxhip_abi_version() != 8 and not ab:
         raise RuntimeError("libfluxhip ABI version mismatch")
     if lib.fluxhip_arch() != b"gfx950":
         raise RuntimeError("libfluxhip was not built for gfx950")

@@ -21,6 +21,8 @@ FLUXHIP_TILES_F8(X)
 
 extern template __global__ void gemm_nt_kernel<256, 256, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>(const GemmParams);
 extern template __global__ void gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>(const GemmParams);
+extern template __global__ void gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_DXR>(const GemmParams);
+extern template __global__ void gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_DXR | FLAG_TIMED>(const GemmParams);
 
 // instantiated in gemm_mx.hip
 #define X(BM, BN, WM, WN, NS, PIPE) extern template __global__ void gemm_nt_kernel<BM, BN, WM, WN, 0, NS, PIPE, FLAG_FP8 | FLAG_LEAN | FLAG_MXA>(const GemmParams);
@@ -225,6 +227,11 @@ const bool g_f16_attached = [] {
 
 bool g_attr_set[kNumCfgs][14] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
+// fluxhip_conv_set_x3_tile: forced tile of the fp32-faithful convs (0: the picker; env FLUXHIP_CONV_X3_CFG) and the halo-tile loader
+// (FLAG_DXR; env FLUXHIP_CONV_DXR=0 switches it off) - A/B timing and tests
+int g_conv_x3_cfg = [] { const char* e = getenv("FLUXHIP_CONV_X3_CFG"); return e ? atoi(e) : 0; }();
+bool g_conv_dxr = [] { const char* e = getenv("FLUXHIP_CONV_DXR"); return !(e && e[0] == '0'); }();
+long long g_conv_dxr_launches = 0;
 
 // Tile choice: a time model per tile, fitted to tools/gemm_tune.py sweeps.
 //   time = t_launch + R(x) * g(x) * (K/64 * t_step + t_fixed),   x = tiles / (256 CUs x blocks/CU)
@@ -550,14 +557,26 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     g_rs_launches += p.sk_mode != 0;
     if (p.sk_mode && !use(c.dense_rs, 5)) return FLUXHIP_ELAUNCH;
   }
-  if (conv && x3 && g_trace && (cfg_idx == 49 || cfg_idx == 52)) {      // diagnostic: the stamped twin of the fp32-faithful conv tile
+  int lds = c.lds;
+  // Halo-tile loader (FLAG_DXR, gemm_core.h): 3 x 3 / stride 1 / pad 1 fp32-faithful convs on the 256 x 128 tile whose tiles are 256
+  // pixels of one image row - the N = 128 layers of the VAE decoders at 512 x 512 and up.  FLUXHIP_CONV_DXR=0: the tap-by-tap loader (A/B).
+  const bool dxr = conv && x3 && cfg_idx == 52 && splits == 1 && g_conv_dxr && p.cv.ksize == 3 && p.cv.stride == 1 && p.cv.pad == 1 &&
+                   !p.cv.ups && !p.cv.sub2 && p.cv.buf && p.cv.Ws % 256 == 0 && p.cv.Ho == p.cv.Hs && p.cv.Wo == p.cv.Ws && p.nbatch == 1;
+  if (dxr) {
+    void (*const dk)(const GemmParams) = g_trace ? gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_DXR | FLAG_TIMED>
+                                                 : gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_DXR>;
+    lds = 2 * 33 * 1024 + 3 * c.bn * 128;       // two halo slots of 264 rows + the weight ring
+    ++g_conv_dxr_launches;
+    if (hipFuncSetAttribute((const void*)dk, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return FLUXHIP_ELAUNCH;
+    fn = dk;
+  } else if (conv && x3 && g_trace && (cfg_idx == 49 || cfg_idx == 52)) {      // diagnostic: the stamped twin of the fp32-faithful conv tile
     void (*const tk)(const GemmParams) = cfg_idx == 49 ? gemm_nt_kernel<256, 256, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>
                                                        : gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>;
     if (hipFuncSetAttribute((const void*)tk, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess) return FLUXHIP_ELAUNCH;
     fn = tk;
   }
   dim3 grid(tm_total * p.tiles_n * splits), block(c.threads);
-  hipLaunchKernelGGL(fn, grid, block, c.lds, s, p);
+  hipLaunchKernelGGL(fn, grid, block, lds, s, p);
   return hipGetLastError() == hipSuccess ? FLUXHIP_OK : FLUXHIP_ELAUNCH;
 }
 
@@ -810,6 +829,14 @@ extern "C" int fluxhip_gemm_set_lean(int on) {
 
 extern "C" int64_t fluxhip_gemm_lean_launches(void) { return g_lean_launches; }
 
+extern "C" int fluxhip_conv_set_x3_tile(int cfg, int dxr) {
+  if (cfg < 0 || (cfg & 0xff) >= kNumCfgs) return FLUXHIP_EINVAL;
+  g_conv_x3_cfg = cfg;
+  if (dxr >= 0) g_conv_dxr = dxr != 0;
+  return FLUXHIP_OK;
+}
+extern "C" int64_t fluxhip_conv_dxr_launches(void) { return g_conv_dxr_launches; }
+
 extern "C" int fluxhip_gemm_set_trace(void* buf) {
   g_trace = (unsigned long long*)buf;
   return FLUXHIP_OK;
@@ -919,7 +946,7 @@ extern "C" int fluxhip_conv2d_x3(const void* x, int64_t x_lo, const void* w, int
   p.w_lo = w_lo;
   p.c_lo = out_lo;
   p.res_lo = res_lo;
-  static const int forced = [] { const char* e = getenv("FLUXHIP_CONV_X3_CFG"); return e ? atoi(e) : 0; }();   // tuning knob
+  const int forced = g_conv_x3_cfg;   // tuning knob
   int cfg = forced > 0 ? forced : pick_cfg(&t.M, 1, 1, Cout, p.K, true, true);
   if (forced <= 0 && ups && (cfg & 0xff) == 49) cfg = (cfg & ~0xff) | 15;
   if (gn_ws) *gn_nchunks = arm_gn_stats(p, cfg, B, Ho * Wo, 1, gn_ws, gn_ws_bytes);

@@ -181,6 +181,11 @@ enum GemmFlags : int {
   // the fp8 loop already uses - lane group kb supplies the 16-byte chunks kb and 4 + kb - so memory K order = MFMA K order.)
   FLAG_MXA = 8,
   FLAG_MXC = 128,
+  // fp32-faithful 3 x 3 / stride 1 / pad 1 convs whose tile is 256 consecutive pixels of ONE image row (Ws % 256 == 0), 256 x 128
+  // ping-pong tile: the three horizontal taps of a filter row read the SAME activation rows shifted by one pixel, so the LDS slot
+  // holds the row segment once with a one-pixel halo (258 rows of 128 B) and the taps are fragment-read offsets - a third of the
+  // activation LDS-DMA of the tap-by-tap loader.  See the DXR block in the ping-pong loop.
+  FLAG_DXR = 4096,
   FLAG_LEAN = 32,    // dense bf16 only: the epilogues, operands and hand-offs the Flux / transformer-block launches use, nothing else compiled in (see gemm.hip lean_ok)
 };
 
@@ -708,6 +713,160 @@ void gemm_nt_kernel(const GemmParams p) {
       // branch inside): every fragment and accumulator register is then written unconditionally in its loop -
       // which keeps hipcc from holding second copies of them - and a wave only carries the address registers
       // of the operand it stages.
+      constexpr bool DXR = (FLAGS & FLAG_DXR) != 0;
+      if constexpr (DXR) {
+        // ---- fp32-faithful 3 x 3 conv, horizontal taps from ONE halo tile (FLAG_DXR) --------------------------------------------
+        // The phase trace of the N = 128 layers at 512 x 512 (tools/conv_phase_trace.py) has BOTH memory phases at twice the MFMA
+        // phases: group 0 issues 8 activation pieces per wave in two of three steps, and a tenth of those lines are first touches
+        // that hold the CU's memory queue for the weight pieces as well.  Per channel chunk and filter row dy the nine K-steps
+        // (3 taps x 3 passes) need only TWO activation tiles - the hi and the lo plane of pixels x0 - 1 .. x0 + 256 of image row
+        // y + dy - 1 - if a tap dx reads its fragments dx rows further down.  K order inside a (chunk, dy) group:
+        //     s = 0..5: tap dx = s / 2, pass s % 2 (hi x hi, hi x lo)   <- slot 0 (hi plane),  s = 6..8: tap dx = s - 6, pass 2 (lo x hi)  <- slot 1
+        // so the hi tile of the NEXT group is staged while the lo tile is consumed (steps 5, 6, 7) and the next lo tile while the
+        // hi tile is (steps 8, 1, 3): 66 pieces per 9 steps instead of 192, at most 3 per wave and phase.  Same sum, another order
+        // of the fp32 accumulation than the tap-by-tap loader.  Launcher: ksize 3, stride 1, pad 1, Ws % 256 == 0, no split-K.
+        static_assert(X3 && AMODE == 1 && BM == 256 && !F8, "FLAG_DXR: fp32-faithful conv, 256-row tile");
+        constexpr int AD_BYTES = 33 * 1024;            // 264 LDS rows (258 used): pixels x0 - 1 .. x0 + 256
+        constexpr int WD_BASE = 2 * AD_BYTES;
+        const int nR = nkt / 9;                         // (chunk, dy) groups of this block (kbase = 0)
+        auto read_dxr = [&](int slot, int dx, int slot_w) {
+          const uint32_t t = (uint32_t)(r16 + dx), sw = t & 7u;
+          const uint32_t ab = lds0 + slot * AD_BYTES + (wm * WTM) * 128 + t * 128u;
+          const uint32_t aa0 = ab + ((((uint32_t)q4) ^ sw) << 4), aa1 = ab + ((((uint32_t)(4 + q4)) ^ sw) << 4);
+          const uint32_t bb0 = lds0 + WD_BASE + slot_w * B_BYTES + (wn * WTN) * 128 + foff[0];
+          const uint32_t bb1 = lds0 + WD_BASE + slot_w * B_BYTES + (wn * WTN) * 128 + foff[1];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a0[i]) : "v"(aa0), "n"(i * 2048) : "memory");
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w0[j]) : "v"(bb0), "n"(j * 2048) : "memory");
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a1[i]) : "v"(aa1), "n"(i * 2048) : "memory");
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w1[j]) : "v"(bb1), "n"(j * 2048) : "memory");
+        };
+        // step s of a group -> (activation slot, tap column)
+        auto slot_of = [](int s_) { return s_ < 6 ? 0 : 1; };
+        auto dx_of = [](int s_) { return s_ < 6 ? (s_ >> 1) : s_ - 6; };
+        if (g0) {
+          // this tile: 256 pixels of image row (img, y) from x0 on
+          const int hw = p.cv.Ho * p.cv.Wo;
+          const int bb = m0 / hw, rem = m0 - bb * hw;
+          const int y = rem / p.cv.Wo, x0 = rem - y * p.cv.Wo;
+          const uint32_t cbias = (uint32_t)((2 * p.cv.Ws + 2) * p.cv.Cin * 2);
+          const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.cv.X - cbias), 0, (int)(uint32_t)(p.cv.x_extent + cbias), 0x00020000);
+          // 9 piece slots per wave (33 pieces over 4 waves: the surplus slots re-fetch piece 32): lane offset of LDS row rho = 8 id + lr,
+          // i.e. pixel (y - 1, x0 - 1 + rho), constant over the loop; a pixel outside the row (or an unused row) is out of range for good
+          uint32_t vo[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            const int id = min(lw + i * LW, 32);
+            const int rho = id * 8 + lr, x = x0 - 1 + rho;
+            const long long pix = ((long long)bb * p.cv.Hs + (y - 1)) * p.cv.Ws + x;
+            vo[i] = (x >= 0 && x < p.cv.Ws && rho < 258) ? (uint32_t)(pix * p.cv.Cin * 2 + lc * 16 + (long long)cbias) : 0xFFFFFFF0u;
+          }
+          // pieces [3 part, 3 part + 3) of the tile (group R, plane) -> slot
+          auto stage_part = [&](int R, int plane, auto part_c) {      // part: compile time, so the unrolled loop below is three straight pieces
+            constexpr int part = decltype(part_c)::value;
+            const int cch = R / 3, dy = R - cch * 3;
+            const bool row_ok = (unsigned)(y + dy - 1) < (unsigned)p.cv.Hs;                    // wave-uniform: a filter row outside the image is zeros
+            const uint32_t soffs = (uint32_t)(((long long)dy * p.cv.Ws * p.cv.Cin + (cch << 6)) * 2 + (plane ? p.a_lo * 2 : 0));
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+              if (i / 3 != part) continue;
+              const int id = min(lw + i * LW, 32);
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void*)(smem + plane * AD_BYTES + id * 1024), 16,
+                                                       row_ok ? vo[i] : 0xFFFFFFF0u, soffs, 0, 0);
+            }
+          };
+          static_for<0, 3>([&](auto P) { stage_part(0, 0, P); stage_part(0, 1, P); });
+          wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+          read_dxr(0, 0, 0);
+          int R = 0, s_ = 0, sw = 0;
+          for (int kt = 0; kt < nkt; ++kt) {
+            const int s1 = s_ == 8 ? 0 : s_ + 1, sw1 = sw == 2 ? 0 : sw + 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GEMM_STAMP(0)
+            __builtin_amdgcn_sched_barrier(0);
+            mma_both();
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_STAMP(1)
+            // my pieces: the hi tile of the next group (issued at steps 5, 6, 7) is first read after B1 of step 8, this group's lo
+            // tile (steps 8, 1, 3) after B1 of step 5 - the only two barriers that have to publish landed pieces
+            if (s_ == 8 || s_ == 5) wait_vmcnt<0>();
+            GEMM_STAMP(2)
+            __builtin_amdgcn_s_barrier();            // B1
+            GEMM_STAMP(3)
+            read_dxr(slot_of(s1), dx_of(s1), sw1);   // (past the last step: a valid slot into registers nobody uses)
+            // hi tile of the next group while this group's lo tile is consumed (its last hi reader was step 5, before B1 above);
+            // lo tile of THIS group during steps 1 and 3, of the next one at step 8 (the last lo reader was step 8, before B1 above)
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            if (s_ == 5) { if (R + 1 < nR) stage_part(R + 1, 0, I0{}); }
+            else if (s_ == 6) { if (R + 1 < nR) stage_part(R + 1, 0, I1{}); }
+            else if (s_ == 7) { if (R + 1 < nR) stage_part(R + 1, 0, I2{}); }
+            else if (s_ == 8) { if (R + 1 < nR) stage_part(R + 1, 1, I0{}); }
+            else if (s_ == 1) { if (R > 0) stage_part(R, 1, I1{}); }
+            else if (s_ == 3) { if (R > 0) stage_part(R, 1, I2{}); }
+            __builtin_amdgcn_s_barrier();            // B2
+            if (s_ == 8) ++R;
+            s_ = s1;
+            sw = sw1;
+          }
+        } else {
+          uint32_t woff[PB];
+          const char* const wbase = (const char*)gW + (long long)b * w_bs * ESZ;
+#pragma unroll
+          for (int i = 0; i < PB; ++i) {
+            const int row = min(lw + i * LW, BPIECES - 1) * 8 + lr;
+            woff[i] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)(K * ESZ) + lc * 16;
+          }
+          // W(kt): group R = kt / 9 -> (chunk, dy), step s -> (dx, pass); the weight column of a tap is tap * Cin + chunk * 64
+          auto stage = [&](int kt, int slot) {
+            const int R = kt / 9, s_ = kt - R * 9;
+            const int cch = R / 3, dy = R - cch * 3;
+            const int dx = s_ < 6 ? (s_ >> 1) : s_ - 6;
+            const bool lo = s_ < 6 && (s_ & 1);
+            const long long koff = ((long long)(dy * 3 + dx) * p.cv.Cin + (cch << 6)) * 2 + (lo ? p.w_lo * 2 : 0);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+              uint32_t wo = woff[i];
+              asm volatile("" : "+v"(wo));
+              glds16(wbase + koff + (size_t)wo, smem + WD_BASE + slot * B_BYTES + min(lw + i * LW, BPIECES - 1) * 1024);
+            }
+          };
+          stage(0, 0);
+          if (nkt > 1) {
+            stage(1, 1);
+            wait_vmcnt<PB>();
+          } else {
+            wait_vmcnt<0>();
+          }
+          __builtin_amdgcn_s_barrier();
+          int s_ = 0, sw = 0;
+          for (int kt = 0; kt < nkt; ++kt) {
+            const int sw1 = sw == 2 ? 0 : sw + 1, sw2 = sw1 == 2 ? 0 : sw1 + 1;
+            read_dxr(slot_of(s_), dx_of(s_), sw);
+            if (kt + 2 < nkt) {
+              stage(kt + 2, sw2);
+              wait_vmcnt<PB>();                      // W(kt+1) landed; W(kt+2) may still fly
+            } else {
+              wait_vmcnt<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GEMM_STAMP(4)
+            __builtin_amdgcn_s_barrier();            // B1
+            GEMM_STAMP(5)
+            __builtin_amdgcn_sched_barrier(0);
+            mma_both();
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_STAMP(6)
+            __builtin_amdgcn_s_barrier();            // B2
+            GEMM_STAMP(7)
+            s_ = s_ == 8 ? 0 : s_ + 1;
+            sw = sw1;
+          }
+        }
+      } else
       if (g0) {
         // ---- group 0: stages the activation tile.  Dense rows as pointers; conv rows as the two packed
         //      geometry registers of the implicit-GEMM loader (same encoding as cyx / cimg above).
@@ -1389,9 +1548,7 @@ void gemm_nt_kernel(const GemmParams p) {
       }
     }
   }
-  // Mode 0, CHAIN.  Release / acquire at agent scope, executed by ONE lane per block: the release (buffer_wbl2) walks the
-  // whole L2, and one per wave made the hand-off cost ~60 us per launch.  Every wave first waits for its
-  // own stores (vmcnt(0)), the block barrier collects them, then lane 0 fences and moves the counter.
+  // Mode 0, CHAIN.  The producer publishes write-through (see below), the consumer acquires at agent scope, ONE lane per block.
   if (!(LEAN && RS_CAPABLE) && S > 1 && !rs) {
     f32x4* part = (f32x4*)(p.sk_part + (size_t)bid * (BM * BN)) + (size_t)wave * (MI * NJ) * 64 + lane;
     int* flag = p.sk_flag + bid;
@@ -1410,16 +1567,21 @@ void gemm_nt_kernel(const GemmParams p) {
         }
     }
     if (sidx < S - 1) {
+      // The partial leaves WRITE-THROUGH (sc1, like the reduce-scatter slabs): the bytes go to memory as they are written, every
+      // storing wave drains its own stores, the block barrier collects the drains and lane 0 moves the counter - no release fence.
+      // (The fence is a buffer_wbl2 that walks an L2 which the other blocks of the XCD are still dirtying: ~6 us per hop.  The
+      // phase trace of the fp32-faithful 64 x 64 convs of the VAE, 256 x 128 tiles with S = 4: 29 us of a 92 us launch in the
+      // three hops.)  cdna guide, Guideline 16 R1; placement independent.
+      const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(p.sk_part + (size_t)bid * (BM * BN), 0, BM * BN * 4, 0x00020000);
+      const int poff = (wave * (MI * NJ)) * 1024 + lane * 16;
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) part[(i * NJ + j) * 64] = acc[i][j];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores are in L2
-      __syncthreads();                                     // ... and everybody else's
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 only: the partial leaves this XCD's L2
-        __hip_atomic_store(flag, sidx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+        for (int j = 0; j < NJ; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), prs, poff + (i * NJ + j) * 1024, 0, /*sc1*/ 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains its write-through stores
+      __syncthreads();                                     // ... all of them have
+      if (tid == 0) __hip_atomic_store(flag, sidx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
     __syncthreads();                                // every wave has consumed the partial

@@ -14,3 +14,6 @@ FLUXHIP_TILES_F8(X)
 // diagnostic: the two ping-pong fp32-faithful conv tiles with phase stamps (fluxhip_gemm_set_trace; tools/conv_phase_trace.py)
 template __global__ void gemm_nt_kernel<256, 256, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>(const GemmParams);
 template __global__ void gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>(const GemmParams);
+// the halo-tile loader of the 3 x 3 fp32-faithful convs whose tile is 256 pixels of one image row (FLAG_DXR, gemm_core.h), + its stamped twin
+template __global__ void gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_DXR>(const GemmParams);
+template __global__ void gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_DXR | FLAG_TIMED>(const GemmParams);

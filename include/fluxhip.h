@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define FLUXHIP_ABI_VERSION 7
+#define FLUXHIP_ABI_VERSION 8
 
 int fluxhip_abi_version(void);
 /* "gfx950" — the only architecture this library is built for. */
@@ -125,6 +125,13 @@ int64_t fluxhip_gemm_lean_launches(void);
 /* Diagnostic: device buffer of [blocks][waves][16] u64 that the phase-timed tile configurations fill with
  * summed s_memtime deltas per main-loop phase (7 phases, iteration count, whole-wave cycles and 100 MHz ticks, setup and epilogue cycles); NULL disables. */
 int fluxhip_gemm_set_trace(void* buf);
+/* Diagnostic (ABI 8): tile of the fp32-faithful convolutions.  cfg > 0 forces a tile configuration (| split-K factor << 8) on
+ * fluxhip_conv2d_x3, 0 returns the choice to the picker.  dxr: 0 / 1 switches the halo-tile loader off / on (-1 leaves it): 3 x 3,
+ * stride 1, pad 1 convolutions on the 256 x 128 tile whose tiles are 256 pixels of ONE image row (Ws % 256 == 0) stage a row segment
+ * once with a one-pixel halo and take the three horizontal taps as fragment-read offsets - a third of the activation traffic of the
+ * tap-by-tap loader, same sum in another fp32 accumulation order.  fluxhip_conv_dxr_launches counts the launches that took it. */
+int fluxhip_conv_set_x3_tile(int cfg, int dxr);
+int64_t fluxhip_conv_dxr_launches(void);
 
 /* Implicit-GEMM convolution, NHWC bf16, weight [Cout][kh][kw][Cin] (MLX nn.Conv2d layout).
  * ksize 1|3, stride 1|2, pad 0|1, ups=1 fuses upsample_nearest(x,(2,2)) into the loader.

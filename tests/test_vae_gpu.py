@@ -165,6 +165,34 @@ def test_conv3x3_x3(dev, Cin, Cout, hw, ups):
     assert rel_l2(ops.join_f32(y3), O.linear(x.double(), w1.double(), b.double()).float()) < X3
 
 
+@pytest.mark.parametrize("Cin,Cout,hw,B", [(128, 128, (5, 256), 2), (256, 128, (3, 512), 1), (64, 96, (2, 256), 1), (128, 128, (1, 256), 1)])
+def test_conv3x3_x3_halo_tile_loader(dev, Cin, Cout, hw, B):
+    """The halo-tile loader of the fp32-faithful 3x3 convs (FLAG_DXR: rows of 256 pixels, the three horizontal taps read from
+    ONE staged row segment): against the float64 convolution (reference: flux/autoencoder.py:70-81 ResnetBlock convs in the
+    checkpoint's float32), with and without the residual, at image borders on every side (row 0 / H - 1, x = 0 / W - 1, the seam
+    between the two tiles of a 512-pixel row), and against the tap-by-tap loader of the same tile (another fp32 summation order)."""
+    from flux_generator_amd import ops, _lib
+    lib = _lib.load()
+    x, w, b = frnd(B, *hw, Cin, seed=11), frnd(Cout, 3, 3, Cin, seed=12, scale=(9 * Cin) ** -0.5), frnd(Cout, seed=13)
+    ref = O.conv2d(x.double(), w.double(), b.double()).float()
+    X, Wt = ops.split_f32(x.to(dev)), ops.split_f32(w.to(dev))
+    res = frnd(*ref.shape, seed=14)
+    try:
+        assert lib.fluxhip_conv_set_x3_tile(52, 1) == 0          # the 256 x 128 ping-pong tile, halo loader on
+        n0 = lib.fluxhip_conv_dxr_launches()
+        y = ops.join_f32(ops.conv2d_x3(X, Wt, b.to(dev)))
+        y2 = ops.join_f32(ops.conv2d_x3(X, Wt, b.to(dev), res=ops.split_f32(res.to(dev))))
+        assert lib.fluxhip_conv_dxr_launches() == n0 + 2, "the launches did not take the halo-tile loader"
+        assert lib.fluxhip_conv_set_x3_tile(52, 0) == 0          # same tile, tap-by-tap loader
+        y_tap = ops.join_f32(ops.conv2d_x3(X, Wt, b.to(dev)))
+        assert lib.fluxhip_conv_dxr_launches() == n0 + 2
+    finally:
+        lib.fluxhip_conv_set_x3_tile(0, 1)
+    assert y.shape == ref.shape and rel_l2(y, ref) < X3 and rel_l2(y2, ref + res) < X3
+    assert float((y.cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-6
+    assert rel_l2(y, y_tap.cpu()) < 1e-6
+
+
 @pytest.mark.parametrize("Cin,Cout,hw,B", [(512, 512, (8, 8), 2), (256, 256, (13, 7), 1), (128, 64, (32, 32), 3), (64, 128, (1, 1), 1)])
 def test_conv_up2x_x3(dev, Cin, Cout, hw, B):
     """Upsample + 3x3 conv in sub-pixel form (four 2x2 convs of the low-res input on pre-summed taps) against the
