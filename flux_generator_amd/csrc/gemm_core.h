@@ -1480,7 +1480,9 @@ void gemm_nt_kernel(const GemmParams p) {
         }
         bcast[0] = gave_up;
         bcast[1] = orphans;
-        if (!gave_up) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv: this CU's L1 may hold last launch's slab lines
+        // (no acquire on the fast path: the peers' partials are read with sc1 loads below - write-through stores on the producing
+        //  side and L1-bypassing loads on this one is a complete hand-off, cdna guide Guideline 16 / correctness table; the fence was a
+        //  buffer_inv on the critical path of every split launch, ~1.7 us behind the last arrival)
       }
       __syncthreads();
       int gave_up = __builtin_amdgcn_readfirstlane(bcast[0]);
@@ -1516,17 +1518,53 @@ void gemm_nt_kernel(const GemmParams p) {
         }
       }
       if constexpr ((FLAGS & FLAG_TIMED) != 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_rs2)::"memory");
-      const f32x4* rd = (const f32x4*)slab + (size_t)wave * F * 64 + lane;
-      for (int s2 = 0; s2 < S; ++s2) {                       // peers in index order (skipping myself): fixed summation order
-        if (s2 == sidx) continue;
-        const f32x4* src = rd + (size_t)s2 * NWAVES * F * 64;
+      // The peers' partials of the fragments this block owns, added in peer order (fixed summation order).  Ownership depends on
+      // (S, split index), run-time values, so every fragment sits behind an "owned?" test - and around a LOAD into registers hipcc
+      // then waits vmcnt(0) before the add that follows: 16 dependent round trips per wave, 7.4 us of every split launch (the
+      // disassembly; the MI355X guide's "register or load" trap).  Dispatching once on (S, split index) makes the owned set a
+      // compile-time list, but its nine instantiations cost the kernel 56 registers and spills into the main loop's budget
+      // (measured: the step got slower).  So the partials travel by LDS-DMA instead (a fragment of a wave is exactly one 1-KiB
+      // piece; sc1 like the loads they replace): a piece needs no destination register and no wait, the tests around them cost
+      // scalar time only, ONE vmcnt(0) lands them all in this wave's own 16 KiB of the dead operand ring, and the adds read them
+      // back from LDS (~100 cycles each instead of a memory round trip).  Up to 16 fragments per round: all peers at once for
+      // S <= 3 on these tiles, peer by peer otherwise.  Same operands in the same order: bit-identical to the register form.
+      {
+        static_assert(4096 + NWAVES * 16384 <= NSA * A_BYTES + NSW * B_BYTES, "reduce-scatter gather area inside the operand ring");
+        char* const gl = smem + 4096 + wave * 16384;          // (the first words of smem are the broadcast words above)
+        const int own = (oi_hi - oi_lo) * (oj_hi - oj_lo);
+        const bool one_round = (S - 1) * own <= 16;
+        const char* const slab_b = (const char*)slab;
+        for (int r0 = 0; r0 < S; r0 = one_round ? S : r0 + 1) {
+          const int r1 = one_round ? S : r0 + 1;
+          int n = 0;
+          for (int s2 = r0; s2 < r1; ++s2) {
+            if (s2 == sidx) continue;
+            const size_t src_off = (size_t)((s2 * NWAVES + wave) * F) * 1024 + lane * 16;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            if (i < oi_lo || i >= oi_hi || j < oj_lo || j >= oj_hi) continue;
-            acc[i][j] += __builtin_nontemporal_load(src + (i * NJ + j) * 64);
+              for (int j = 0; j < NJ; ++j) {
+                if (i < oi_lo || i >= oi_hi || j < oj_lo || j >= oj_hi) continue;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slab_b + src_off + (i * NJ + j) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(gl + n * 1024), 16, 0, /*sc1*/ 16);
+                ++n;
+              }
           }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces have landed (only this wave reads them: no barrier)
+          n = 0;
+          for (int s2 = r0; s2 < r1; ++s2) {
+            if (s2 == sidx) continue;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) {
+                if (i < oi_lo || i >= oi_hi || j < oj_lo || j >= oj_hi) continue;
+                acc[i][j] += *(const f32x4*)(gl + n * 1024 + lane * 16);
+                ++n;
+              }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next round (or the epilogue) reuses the area
+        }
       }
       if constexpr ((FLAGS & FLAG_TIMED) != 0) {
         asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_rs3)::"memory");
@@ -1945,7 +1983,10 @@ void gemm_nt_kernel(const GemmParams p) {
     if (rs_orphans != 0) {
       constexpr int F = MI * NJ;
       const bool by_rows = (MI % S) == 0;
-      const f32x4* rd = (const f32x4*)(p.sk_part + (size_t)bid * ((size_t)S * BM * BN)) + (size_t)wave * F * 64 + lane;
+      const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.sk_part + (size_t)bid * ((size_t)S * BM * BN), 0, S * BM * BN * 4, 0x00020000);
+      auto slab_ld = [&](int src, int frag) {      // fragment `frag` of this wave in the partial of split `src`: sc1 load (L1 bypass, like the fast path)
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ((src * NWAVES + wave) * F + frag) * 1024 + lane * 16, 0, 16));
+      };
       for (int so = 0; so < S; ++so) {
         if (((rs_orphans >> so) & 1) == 0) continue;
         int ai_lo = 0, ai_hi = MI, aj_lo = 0, aj_hi = NJ;
@@ -1956,9 +1997,9 @@ void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             if (i < ai_lo || i >= ai_hi || j < aj_lo || j >= aj_hi) continue;      // wave-uniform
-            f32x4 sum = __builtin_nontemporal_load(rd + (size_t)so * NWAVES * F * 64 + (i * NJ + j) * 64);
+            f32x4 sum = slab_ld(so, i * NJ + j);
             for (int s2 = 0; s2 < S; ++s2)
-              if (s2 != so) sum += __builtin_nontemporal_load(rd + (size_t)s2 * NWAVES * F * 64 + (i * NJ + j) * 64);
+              if (s2 != so) sum += slab_ld(s2, i * NJ + j);
             acc[i][j] = sum;
             const int m = m0 + wm * WTM + i * 16 + r16, n4 = n0 + wn * WTN + j * 16 + q4 * 4;
             if (m >= Mg || n4 >= N) continue;
