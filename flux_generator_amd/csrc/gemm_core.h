@@ -1646,46 +1646,74 @@ void gemm_nt_kernel(const GemmParams p) {
     float gs[NJ], gq[NJ];                          // GroupNorm partials of this lane's column quads (p.gn_ws)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) gs[j] = gq[j] = 0.f;
+    // Operands first, arithmetic after (round 5).  With the bias and residual loads inside the (i, j) loops behind the row / column
+    // range tests, hipcc branched around every load and waited vmcnt(0) before its use: two dependent round trips per fragment,
+    // 32 per wave on the 256 x 128 tile = the 10 us (256 x 256: 21 us) this epilogue took per tile in tools/conv_phase_trace.py.
+    // Now: the column bias of all NJ fragments in one batch (clamped column, no branch), and per row block the 2 NJ residual
+    // loads in one batch (clamped row / column); only the stores are predicated.
+    f32x4 bj[NJ];
+    bool jok[NJ];
+    int n4c[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
+      jok[j] = n4 < N;
+      n4c[j] = jok[j] ? n4 : 0;
+      bj[j] = (fbias && !p.row_bias) ? *(const f32x4*)(fbias + n4c[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float rbi[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) rbi[i] = (fbias && p.row_bias) ? fbias[min(m0 + wm * WTM + i * 16 + r16, Mg - 1)] : 0.f;
+    const bool with_res = !p.out_f32 && epi == EPI_GATE_RES;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * WTM + i * 16 + r16;
-      if (m >= Mg) continue;
-      const float rb = (fbias && p.row_bias) ? fbias[m] : 0.f;
-      long long orow = m;
+      const bool iok = m < Mg;
+      const int mc = iok ? m : Mg - 1;
+      long long orow = mc;
       if (AMODE == 1 && p.cv.sub2) {               // sub-pixel conv: (b, y, x) -> (b, 2y + sdy, 2x + sdx)
         const int hw = p.cv.Ho * p.cv.Wo;
-        const int bb = m / hw, rem = m - bb * hw;
+        const int bb = mc / hw, rem = mc - bb * hw;
         const int y = rem / p.cv.Wo, x = rem - y * p.cv.Wo;
         orow = ((long long)bb * (2 * p.cv.Ho) + 2 * y + sdy) * (2 * p.cv.Wo) + 2 * x + sdx;
       }
+      const long long rowbase = (long long)b * c_bs + orow * p.ldc;
+      u32x2 rh[NJ], rl[NJ];
+      if (with_res) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          rh[j] = *(const u32x2*)(gRes + rowbase + n4c[j]);
+          rl[j] = *(const u32x2*)(gRes + rowbase + n4c[j] + p.res_lo);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int n4 = n0 + wn * WTN + j * 16 + q4 * 4;
-        if (n4 >= N) continue;
         f32x4 v = acc[i][j] * alpha;
-        if (fbias && !p.row_bias) v += *(const f32x4*)(fbias + n4);
-        v += rb;
-        const long long idx = (long long)b * c_bs + orow * p.ldc + n4;
+        v += bj[j];
+        v += rbi[i];
+        const long long idx = rowbase + n4c[j];
+        const bool ok = iok && jok[j];
         if (p.out_f32) {
-          *(f32x4*)((float*)gC + idx) = v;
+          if (ok) *(f32x4*)((float*)gC + idx) = v;
           continue;
         }
-        if (epi == EPI_GATE_RES) {
-          const u32x2 rh = *(const u32x2*)(gRes + idx), rl = *(const u32x2*)(gRes + idx + p.res_lo);
-          v[0] += e_lo<F16>(rh[0]) + e_lo<F16>(rl[0]);
-          v[1] += e_hi<F16>(rh[0]) + e_hi<F16>(rl[0]);
-          v[2] += e_lo<F16>(rh[1]) + e_lo<F16>(rl[1]);
-          v[3] += e_hi<F16>(rh[1]) + e_hi<F16>(rl[1]);
+        if (with_res) {
+          v[0] += e_lo<F16>(rh[j][0]) + e_lo<F16>(rl[j][0]);
+          v[1] += e_hi<F16>(rh[j][0]) + e_hi<F16>(rl[j][0]);
+          v[2] += e_lo<F16>(rh[j][1]) + e_lo<F16>(rl[j][1]);
+          v[3] += e_hi<F16>(rh[j][1]) + e_hi<F16>(rl[j][1]);
         }
         u32x2 oh, ol;
         oh[0] = e_pack<F16>(v[0], v[1]);
         oh[1] = e_pack<F16>(v[2], v[3]);
         ol[0] = e_pack<F16>(v[0] - e_lo<F16>(oh[0]), v[1] - e_hi<F16>(oh[0]));
         ol[1] = e_pack<F16>(v[2] - e_lo<F16>(oh[1]), v[3] - e_hi<F16>(oh[1]));
-        *(u32x2*)(gC + idx) = oh;
-        *(u32x2*)(gC + idx + p.c_lo) = ol;
-        gs[j] += (v[0] + v[1]) + (v[2] + v[3]);
-        gq[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        if (ok) {
+          *(u32x2*)(gC + idx) = oh;
+          *(u32x2*)(gC + idx + p.c_lo) = ol;
+          gs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+          gq[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
       }
     }
     if (AMODE == 1 && p.gn_ws) {
