@@ -1751,7 +1751,9 @@ void gemm_nt_kernel(const GemmParams p) {
 
   if (!bias_loaded) load_bias();
   // (ADDVEC is a compile-time tag so the common path carries no per-tile branch or integer division)
-  auto biased = [&](auto addvec_tag, int i, int j, int m, int n4, float (&v)[4]) {
+  // (aw_pre: the addend of this fragment already in registers - phase A of the LDS-transposed epilogue requests the NJ addends of a
+  //  row block in one batch; as a load inside the fragment loop every one of them was followed by vmcnt(0), see phase_a)
+  auto biased = [&](auto addvec_tag, int i, int j, int m, int n4, float (&v)[4], const u32x2* aw_pre = nullptr) {
     if constexpr (F8) {
       v[0] = acc[i][j][0] * (asc[i] * wsc[j][0]) + (e_lo<F16>(bcol[j][0]) + brow[i]);
       v[1] = acc[i][j][1] * (asc[i] * wsc[j][1]) + (e_hi<F16>(bcol[j][0]) + brow[i]);
@@ -1765,8 +1767,9 @@ void gemm_nt_kernel(const GemmParams p) {
     }
     if constexpr (decltype(addvec_tag)::value) {   // per-image vector added after the bias (ResnetBlock2D: + temb[:, None, None, :])
       // ... or a whole matrix addend of this group (the low-rank branch of an unfused LoRA layer): row m of batch b
-      u32x2 aw = gAddm ? *(const u32x2*)(gAddm + (long long)b * addm_bs + (long long)m * p.addvec_stride + n4)
-                       : *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
+      u32x2 aw = aw_pre ? *aw_pre
+                 : gAddm ? *(const u32x2*)(gAddm + (long long)b * addm_bs + (long long)m * p.addvec_stride + n4)
+                         : *(const u32x2*)(p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride + n4);
       v[0] = e_rnd<F16>(v[0]) + e_lo<F16>(aw[0]);
       v[1] = e_rnd<F16>(v[1]) + e_hi<F16>(aw[0]);
       v[2] = e_rnd<F16>(v[2]) + e_lo<F16>(aw[1]);
@@ -1828,6 +1831,15 @@ void gemm_nt_kernel(const GemmParams p) {
         }
         const int row = i * 16 + r16;
         const int m = min(m0 + wm * WTM + row, Mg - 1);
+        // the addends of this row block (ResnetBlock2D's temb vector / an unfused LoRA branch): one batch of NJ loads, one row
+        // decode - inside the fragment loop each load was followed by vmcnt(0) and each fragment repeated the division
+        u32x2 awv[decltype(addvec_tag)::value ? NJ : 1];
+        if constexpr (decltype(addvec_tag)::value) {
+          const bf16_t* const ap = gAddm ? gAddm + (long long)b * addm_bs + (long long)m * p.addvec_stride
+                                         : p.addvec + (long long)(m / p.addvec_rows) * p.addvec_stride;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) awv[j] = *(const u32x2*)(ap + min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4));
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           if constexpr (decltype(sub_tag)::value) {
@@ -1835,6 +1847,8 @@ void gemm_nt_kernel(const GemmParams p) {
           }
           const int n4 = min(n0 + wn * WTN + j * 16 + q4 * 4, N - 4);
           float v[4];
+          if constexpr (decltype(addvec_tag)::value) biased(addvec_tag, i, j, m, n4, v, &awv[j]);
+          else
           biased(addvec_tag, i, j, m, n4, v);
           u32x2 o;
           o[0] = e_pack<F16>(v[0], v[1]);
