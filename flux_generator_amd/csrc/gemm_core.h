@@ -870,7 +870,6 @@ void gemm_nt_kernel(const GemmParams p) {
       if (g0) {
         // ---- group 0: stages the activation tile.  Dense rows as pointers; conv rows as the two packed
         //      geometry registers of the implicit-GEMM loader (same encoding as cyx / cimg above).
-        const char* src[PA];
         uint32_t soff[PA];                 // dense rows: byte offset from the (wave-uniform) base of this group / batch
         const char* const abase = (const char*)gA + (long long)b * a_bs * ESZ;
         int gyx[PA];
@@ -883,7 +882,6 @@ void gemm_nt_kernel(const GemmParams p) {
           const int row = (lw + i * LW) * 8 + lr;
           const int grow = min(m0 + row, Mg - 1);
           if (AMODE == 0) {
-            src[i] = nullptr;
             soff[i] = (uint32_t)grow * (uint32_t)(p.lda * ESZ) + lc * 16;      // < 4 GiB per (group, batch): checked by the launcher
           } else {
             const int hw = p.cv.Ho * p.cv.Wo;
