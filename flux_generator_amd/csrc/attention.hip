@@ -378,78 +378,121 @@ __global__ __launch_bounds__(NW * KS * 64, KS == 1 ? 2 : 1) void attn_kernel(con
     __syncthreads();
   }
 
-  // ---- KS = 2: fold the odd-tile state into the even-tile wave of the same queries --------------
-  if (KS == 2) {
-    float* mrg = (float*)smem + (size_t)qw * (NDB * 16 + 2) * 64 + lane;   // [qw][reg][lane], after the last barrier
-    if (kp == 1) {
+  // ---- finalize: O[q][d] = O^T[d][q] / l for the d-blocks [LO, HI) of this wave ---------------------
+  // Stores: a lane holds 4 consecutive d of its query per register group, its partner (lane ^ 32) the next 4; one
+  // v_permlane32_swap per dword and group PAIR gives every lane 16 contiguous bytes - half the store instructions of the
+  // 8-byte form (the store tail of this layout is issue-bound: MI355X guide, T21).
+  auto finalize = [&](auto LOc, auto HIc) {
+    constexpr int LO = decltype(LOc)::value, HI = decltype(HIc)::value;
+    const float l_tot = pair32_sum(l_run);
+    const float inv = 1.f / l_tot;
+    const int q = q0 + ql;
+    if constexpr (MXO) {
+      // e4m3 + one E8M0 scale per 32 output columns: block db of query q is the 16 values of this lane and the 16 of lane ^ 32
+      // (the arithmetic of the FLAG_MXC GEMM epilogue: 2^e = smallest power of two with max|v| / 2^e <= 448)
+      const long long grow = (long long)b * Tq + min(q, Tq - 1);
+      uint8_t* orow8 = p.O8 + grow * p.ldo + h * HD;
 #pragma unroll
-      for (int i = 0; i < NDB; ++i)
+      for (int db = LO; db < HI; ++db) {
+        float v[16];
+        float am = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mrg[(i * 16 + r) * 64] = oT[i][r];
-      mrg[(NDB * 16) * 64] = m_run;
-      mrg[(NDB * 16 + 1) * 64] = l_run;
+        for (int r = 0; r < 16; ++r) { v[r] = oT[db][r] * inv; am = fmaxf(am, fabsf(v[r])); }
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        const uint32_t ab = __builtin_bit_cast(uint32_t, am);
+        int e8 = (int)(ab >> 23) - 8 + (int)((ab & 0x7fffffu) > 0x600000u);
+        e8 = min(max(e8, 1), 253);
+        const float mul = __builtin_bit_cast(float, (uint32_t)(254 - e8) << 23);
+        if (q < Tq) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[rg * 4 + 0] * mul, v[rg * 4 + 1] * mul, w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[rg * 4 + 2] * mul, v[rg * 4 + 3] * mul, w, true);
+            *(uint32_t*)(orow8 + db * 32 + 8 * rg + 4 * hi) = (uint32_t)w;
+          }
+          if (hi == 0) {
+            const int kb = h * (HD / 32) + db;
+            p.mx[((((long long)(kb >> 2) * p.mx_kstride + (grow >> 6) * 64 + (kb & 3) * 16 + (grow & 15)) << 2) + ((grow >> 4) & 3))] = (uint8_t)e8;
+          }
+        }
+      }
+    } else {
+      bf16_t* orow = p.O + ((long long)b * Tq + min(q, Tq - 1)) * p.ldo + h * HD;
+      const bool wide_o = ((p.ldo & 7) == 0) && (((uintptr_t)p.O & 15) == 0);      // 16-byte addressable rows (wave-uniform)
+      if (!wide_o) {                             // the interface only asks for ldo % 4 == 0: 8-byte stores from the MFMA layout
+#pragma unroll
+        for (int db = LO; db < HI; ++db)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            u32x2 o;
+            o[0] = e_pack<F16>(oT[db][rg * 4 + 0] * inv, oT[db][rg * 4 + 1] * inv);
+            o[1] = e_pack<F16>(oT[db][rg * 4 + 2] * inv, oT[db][rg * 4 + 3] * inv);
+            if (q < Tq) *(u32x2*)(orow + db * 32 + 8 * rg + 4 * hi) = o;
+          }
+        return;
+      }
+#pragma unroll
+      for (int db = LO; db < HI; ++db)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg += 2) {
+          u32x2 oa, ob;                          // groups rg (d = 8 rg + 4 hi ..) and rg + 1 of this lane
+          oa[0] = e_pack<F16>(oT[db][rg * 4 + 0] * inv, oT[db][rg * 4 + 1] * inv);
+          oa[1] = e_pack<F16>(oT[db][rg * 4 + 2] * inv, oT[db][rg * 4 + 3] * inv);
+          ob[0] = e_pack<F16>(oT[db][rg * 4 + 4] * inv, oT[db][rg * 4 + 5] * inv);
+          ob[1] = e_pack<F16>(oT[db][rg * 4 + 6] * inv, oT[db][rg * 4 + 7] * inv);
+          // lanes 0-31 end up with [own group rg | partner's group rg], lanes 32-63 with [partner's group rg + 1 | own group rg + 1]
+          const auto s0 = __builtin_amdgcn_permlane32_swap(oa[0], ob[0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(oa[1], ob[1], false, false);
+          if (q < Tq) *(u32x4*)(orow + db * 32 + 8 * (rg + hi)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
     }
-    __syncthreads();
-    if (kp == 1) return;
-    const float m_b = mrg[(NDB * 16) * 64], l_b = mrg[(NDB * 16 + 1) * 64];
-    const float m_new = fmaxf(m_run, m_b);
-    const float fa = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);
-    const float fb = __builtin_amdgcn_exp2f((m_b - m_new) * scale_log2);
-    l_run = l_run * fa + l_b * fb;
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oT[i][r] = oT[i][r] * fa + mrg[(i * 16 + r) * 64] * fb;
-  }
+  };
+  using D0 = std::integral_constant<int, 0>;
+  using DH = std::integral_constant<int, NDB / 2>;
+  using DN = std::integral_constant<int, NDB>;
 
-  // ---- finalize: O[q][d] = O^T[d][q] / l -----------------------------------------
-  const float l_tot = pair32_sum(l_run);
-  const float inv = 1.f / l_tot;
-  const int q = q0 + ql;
-  if constexpr (MXO) {
-    // e4m3 + one E8M0 scale per 32 output columns: block db of query q is the 16 values of this lane and the 16 of lane ^ 32
-    // (the arithmetic of the FLAG_MXC GEMM epilogue: 2^e = smallest power of two with max|v| / 2^e <= 448)
-    const long long grow = (long long)b * Tq + min(q, Tq - 1);
-    uint8_t* orow8 = p.O8 + grow * p.ldo + h * HD;
+  // ---- KS = 2: the two wave sets hold partial (max, sum, O^T) states of the same queries over the even / odd KV tiles.
+  // Each set FINISHES HALF of the head dimension: it hands the other half of its O^T (and its max / sum) to its partner through
+  // LDS in 16-byte pieces, merges the half it keeps and stores it - both sets work, each moves 34 values per lane instead of
+  // one set writing 66 and the other reading them back one dword at a time (round 5; the tail of a 20-tile workgroup at T = 1280
+  // is a tenth of its time).
+  if constexpr (KS == 2) {
+    static_assert(NDB % 2 == 0, "two wave sets split the head dimension in halves");
+    constexpr int HB = NDB / 2, SLOTS = HB * 4 + 1;          // f32x4 slots per lane: HB d-blocks of 16 values + (max, sum)
+    f32x4* const mine = (f32x4*)smem + (size_t)((qw * 2 + kp) * SLOTS) * 64 + lane;        // [qw][writer set][slot][lane], after the last barrier
+    const f32x4* const theirs = (const f32x4*)smem + (size_t)((qw * 2 + (1 - kp)) * SLOTS) * 64 + lane;
+    auto hand_over = [&](auto GIVEc) {
+      constexpr int GIVE = decltype(GIVEc)::value;
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-      float v[16];
-      float am = 0.f;
+      for (int i = 0; i < HB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { v[r] = oT[db][r] * inv; am = fmaxf(am, fabsf(v[r])); }
-      am = fmaxf(am, __shfl_xor(am, 32, 64));
-      const uint32_t ab = __builtin_bit_cast(uint32_t, am);
-      int e8 = (int)(ab >> 23) - 8 + (int)((ab & 0x7fffffu) > 0x600000u);
-      e8 = min(max(e8, 1), 253);
-      const float mul = __builtin_bit_cast(float, (uint32_t)(254 - e8) << 23);
-      if (q < Tq) {
+        for (int r4 = 0; r4 < 4; ++r4)
+          mine[(i * 4 + r4) * 64] = f32x4{oT[GIVE + i][r4 * 4], oT[GIVE + i][r4 * 4 + 1], oT[GIVE + i][r4 * 4 + 2], oT[GIVE + i][r4 * 4 + 3]};
+      mine[(HB * 4) * 64] = f32x4{m_run, l_run, 0.f, 0.f};
+    };
+    if (kp == 0) hand_over(DH{}); else hand_over(D0{});      // set 0 keeps the low half of d, set 1 the high half
+    __syncthreads();
+    const f32x4 ml = theirs[(HB * 4) * 64];
+    const float m_new = fmaxf(m_run, ml[0]);
+    const float fa = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);
+    const float fb = __builtin_amdgcn_exp2f((ml[0] - m_new) * scale_log2);
+    l_run = l_run * fa + ml[1] * fb;
+    auto take = [&](auto KEEPc) {
+      constexpr int KEEP = decltype(KEEPc)::value;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          int w = 0;
-          w = __builtin_amdgcn_cvt_pk_fp8_f32(v[rg * 4 + 0] * mul, v[rg * 4 + 1] * mul, w, false);
-          w = __builtin_amdgcn_cvt_pk_fp8_f32(v[rg * 4 + 2] * mul, v[rg * 4 + 3] * mul, w, true);
-          *(uint32_t*)(orow8 + db * 32 + 8 * rg + 4 * hi) = (uint32_t)w;
+      for (int i = 0; i < HB; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 t = theirs[(i * 4 + r4) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) oT[KEEP + i][r4 * 4 + e] = oT[KEEP + i][r4 * 4 + e] * fa + t[e] * fb;
         }
-        if (hi == 0) {
-          const int kb = h * (HD / 32) + db;
-          p.mx[((((long long)(kb >> 2) * p.mx_kstride + (grow >> 6) * 64 + (kb & 3) * 16 + (grow & 15)) << 2) + ((grow >> 4) & 3))] = (uint8_t)e8;
-        }
-      }
-    }
-    return;
-  }
-  if (q < Tq) {
-    bf16_t* orow = p.O + ((long long)b * Tq + q) * p.ldo + h * HD;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d0 = db * 32 + 8 * rg + 4 * hi;
-        u32x2 o;
-        o[0] = e_pack<F16>(oT[db][rg * 4 + 0] * inv, oT[db][rg * 4 + 1] * inv);
-        o[1] = e_pack<F16>(oT[db][rg * 4 + 2] * inv, oT[db][rg * 4 + 3] * inv);
-        *(u32x2*)(orow + d0) = o;
-      }
+    };
+    if (kp == 0) { take(D0{}); finalize(D0{}, DH{}); }
+    else { take(DH{}); finalize(DH{}, DN{}); }
+  } else {
+    finalize(D0{}, DN{});
   }
 }
 
