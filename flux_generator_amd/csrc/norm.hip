@@ -296,7 +296,14 @@ static int ln_modulate_launch(const void* x, void* out, float* row_scale, int B,
                          (const bf16_t*)shift_txt, (const bf16_t*)scale_txt, (const bf16_t*)shift_img,  \
                          (const bf16_t*)scale_img, (long long)mod_bstride, eps, (float*)nullptr);       \
   } while (0)
-  if (D >= 2048) {
+  if (D >= 2048 && rows >= 8192) {
+    // many rows (the fp8 configuration at batch 4: 17408; at 4608 rows the row-per-workgroup form is level): ONE wave per row, four rows per workgroup - no
+    // block barrier between the three reductions of a row; with a row per workgroup the launch was a queue of 17408
+    // latency-bound workgroups (56 us for 160 MB at C5's shape = 2.8 TB/s)
+    grid = dim3((unsigned)((rows + 3) / 4)); block = dim3(256);
+    if (D <= 3072) LN_LAUNCH(6, 1);
+    else LN_LAUNCH(8, 1);
+  } else if (D >= 2048) {
     // four waves per row, one row per 256-thread workgroup: 1280 rows -> 1280 workgroups, 20 waves per CU
     grid = dim3((unsigned)rows); block = dim3(256);
     LN_LAUNCH(2, 4);
