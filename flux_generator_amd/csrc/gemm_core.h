@@ -282,7 +282,22 @@ void gemm_nt_kernel(const GemmParams p) {
   }
   const int TM = p.tiles_m_total;
   int tm = swz % TM;
-  const int tn = swz / TM;
+  int tn = swz / TM;
+  // Many M-tiles (Flux-dev 1024^2: 18, the fp8 configuration at batch 4: 68): bands of GN N-tiles, inside a band the N-tile runs
+  // fastest - the ~32 tiles an XCD has in flight are then ~8 M-tiles x 4 N-tiles (8 activation + 4 weight panels in its L2)
+  // instead of 32 M-tiles of ONE N-tile (32 + 1 panels): the activation operand, which no longer fits any cache at these
+  // sizes, is read once per band instead of once per N-tile.  (At batch 1 - 5 M-tiles - the order below is unchanged.)
+#ifndef FLUXHIP_TILE_BAND
+#define FLUXHIP_TILE_BAND 4
+#endif
+  if (AMODE == 0 && FLUXHIP_TILE_BAND > 1 && TM >= 16 && !rs_map) {
+    constexpr int GN = FLUXHIP_TILE_BAND;
+    const int band = swz / (TM * GN), first = band * GN;
+    const int gn = min(GN, p.tiles_n - first);
+    const int r = swz - band * (TM * GN);
+    tm = r / gn;
+    tn = first + (r - tm * gn);
+  }
 
   const int tm0 = p.nbatch * p.g[0].tiles_m;
   const bool g1 = tm >= tm0;
