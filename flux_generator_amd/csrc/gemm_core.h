@@ -290,8 +290,10 @@ void gemm_nt_kernel(const GemmParams p) {
 #ifndef FLUXHIP_TILE_BAND
 #define FLUXHIP_TILE_BAND 4
 #endif
-  if (AMODE == 0 && FLUXHIP_TILE_BAND > 1 && TM >= 16 && !rs_map) {
-    constexpr int GN = FLUXHIP_TILE_BAND;
+  if (FLUXHIP_TILE_BAND > 1 && TM >= 16 && !rs_map) {      // (convs: the N-tiles of one pixel window share its im2col reads)
+    // (long K - the N = 3072 projections back into the residual stream - measured 3 % better with bands of 8: their weight panel
+    //  per N-tile is the larger operand stream)
+    const int GN = p.K >= 8192 ? 2 * FLUXHIP_TILE_BAND : FLUXHIP_TILE_BAND;
     const int band = swz / (TM * GN), first = band * GN;
     const int gn = min(GN, p.tiles_n - first);
     const int r = swz - band * (TM * GN);
