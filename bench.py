@@ -123,6 +123,52 @@ def pmc_traffic(label: str, workload: str) -> dict:
             "traffic_source": f"profiles/{os.path.basename(path)}: {best['kernel']}"}
 
 
+def private_l2_floor(flow, ws, label: str):
+    """Bytes per launch (mean over the launches labelled `label`) that MUST cross the L2 -> fabric boundary FETCH_SIZE /
+    WRITE_SIZE count, given 8 XCDs with private L2s and the kernel's own block -> tile map (gemm_core.h, reduce-scatter
+    brick map: blocks in (split, N-tile, M-tile) order, M fastest, cut into 8 contiguous ranges): per XCD the distinct
+    (split, M-tile) activation panels and (split, N-tile) weight panels of its range, once each; the output, the
+    residual, and for S > 1 the fp32 partials a block writes through for its S - 1 peers and reads back from them.
+    None for labels that are not split-K bf16 GEMMs (the unsplit maps differ)."""
+    import ctypes, re
+    from flux_generator_amd import _lib
+    lib = _lib.load()
+    m = re.search(r"cfg(\d+)s(\d+)$", label)
+    if not m:
+        return None
+    cfg, S = int(m.group(1)), int(m.group(2))
+    bm, bn, th = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    if lib.fluxhip_gemm_tile_shape(cfg, bm, bn, th) != 0:
+        return None
+    bm, bn = bm.value, bn.value
+    tot, cnt = 0.0, 0
+    for fn, a in ws["plan"]:
+        if getattr(fn, "__name__", "") != "fluxhip_gemm_bf16":
+            continue
+        code = lib.fluxhip_gemm_tile_cfg(a[0])
+        if (code & 255) != cfg or (code >> 8) != S:
+            continue
+        d = a[0]._obj
+        tm = sum((d.g[i].M + bm - 1) // bm for i in range(d.ngroups)) * d.nbatch
+        tn = (d.N + bn - 1) // bn
+        nblk = tm * tn * S
+        kb = d.K // S * 2                                   # bytes of one panel row over one K range
+        byts, q8, r8, lo = 0.0, nblk // 8, nblk % 8, 0
+        for x in range(8):
+            hi = lo + q8 + (1 if x < r8 else 0)
+            pa, pw = set(), set()
+            for lin in range(lo, hi):
+                s_, t = divmod(lin, tm * tn)
+                pa.add((s_, t % tm)); pw.add((s_, t // tm))
+            byts += len(pa) * bm * kb + len(pw) * bn * kb
+            lo = hi
+        m_total = sum(d.g[i].M for i in range(d.ngroups)) * d.nbatch
+        byts += 2.0 * m_total * d.N * (2 if d.g[0].res else 1)                       # output (+ residual)
+        byts += 2.0 * nblk * bm * bn * 4.0 * (S - 1) / S                              # partials: written through + read back
+        tot += byts; cnt += 1
+    return tot / cnt if cnt else None
+
+
 def time_other_configs(pipe, dev, reps: int = 3) -> list:
     """One driver-timed line per remaining BASELINE.json config, measured inside the headline run (N = 1, rank 0), after
     the headline's own measurements: C5's per-GPU shape (Flux-schnell fp8 blocks, 1024x1024, batch 4), C3 (Flux-dev
@@ -314,6 +360,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C4 / C5 lines (`other_configs`) of the default N = 1 run")
     ap.add_argument("--profile-only", action="store_true", help="run a few steps for rocprofv3, print nothing else")
+    ap.add_argument("--dump-plan-bytes", default=None, metavar="PATH", help="with --profile-only: write the algorithmic HBM bytes per launch "
+                    "of every GEMM tile configuration of the plan (JSON) - tools/pmc_summary.py puts them next to the counter bytes")
     ap.add_argument("--guidance", type=float, default=None, help="default 4.0 (7.0 for flux-dev, BASELINE.json configs[2])")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo skeleton of the N-rank job: launch, sharding, broadcast, "
                     "barrier, max-reduce and gather, no kernels (tests/test_distributed_cpu.py)")
@@ -413,6 +461,25 @@ def main() -> None:
         for _ in range(args.steps):
             one_pass()
         torch.cuda.synchronize()
+        if args.dump_plan_bytes:
+            import ctypes
+            from flux_generator_amd import _lib
+            ws = pipe.flow._workspace(B, S, L)
+            agg = {}
+            for label, _, _, nb in pipe.flow.profile_plan(ws, with_bytes=True):
+                a = agg.setdefault(label, [0, 0.0])
+                a[0] += 1; a[1] += nb
+            out = {}
+            for label, (cnt, nb) in agg.items():
+                ent = {"launches_per_forward": cnt, "algorithmic_MB_per_launch": nb / cnt / 1e6 if nb else None}
+                mm = __import__("re").search(r"cfg(\d+)", label)
+                if mm:
+                    bm, bn, th = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                    if _lib.load().fluxhip_gemm_tile_shape(int(mm.group(1)), bm, bn, th) == 0:
+                        ent.update(bm=bm.value, bn=bn.value)
+                out[label] = ent
+            with open(args.dump_plan_bytes, "w") as f:
+                json.dump({"workload": f"{args.model} B{B} T{L + S}", "labels": out}, f, indent=1)
         return
     sync_all()
     t0 = time.perf_counter()
@@ -496,19 +563,32 @@ def main() -> None:
 
     # ---- roofline of the dominant kernel: per-launch HIP events over one eager pass of the plan
     ws = pipe.flow._workspace(B, S, L)
-    recs = pipe.flow.profile_plan(ws)
-    recs = pipe.flow.profile_plan(ws)
+    recs = pipe.flow.profile_plan(ws, with_bytes=True)
+    recs = pipe.flow.profile_plan(ws, with_bytes=True)
     by = {}
-    for label, ms, fl in recs:
-        a = by.setdefault(label, [0, 0.0, 0.0])
-        a[0] += 1; a[1] += ms; a[2] += fl
+    for label, ms, fl, nb in recs:
+        a = by.setdefault(label, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += fl; a[3] += nb
     dom = max(by, key=lambda k: by[k][1])
-    n, ms, fl = by[dom]
+    n, ms, fl, nb = by[dom]
     ach = fl / (ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": dom, "launches_per_forward": n, "avg_launch_ms": ms / n,
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "algorithmic_flop_per_launch": fl / n}
+                "algorithmic_flop_per_launch": fl / n,
+                "algorithmic_bytes_per_launch": (nb / n) if nb else None}
     roofline.update(pmc_traffic(dom, f"{args.model} B{B} T{L + S}"))
+    if roofline.get("traffic") and nb:
+        # counter bytes / algorithmic bytes of the same launches: a regression in re-reads shows here (tools/pmc_summary.py writes
+        # the same ratio per kernel into profiles/rNN_hbm_traffic_pmc.csv)
+        roofline["traffic_ratio"] = roofline["traffic"] / (nb / n)
+        floor = private_l2_floor(pipe.flow, ws, dom)
+        if floor:
+            roofline["traffic_floor_8_private_l2"] = floor
+            roofline["traffic_over_floor"] = roofline["traffic"] / floor
+            roofline["traffic_note"] = ("FETCH_SIZE / WRITE_SIZE count requests on the fabric side of the 8 per-XCD L2s, Infinity-Cache hits "
+                                        "included (MI355X_MICROARCH.md, HBM): `traffic_floor_8_private_l2` is what the launch's own brick map "
+                                        "must move at that boundary - every XCD its K range of the activation panel and its own weight "
+                                        "panels, plus the split-K partials written through and read back - DESIGN.md 3.1")
     breakdown = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": (round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None)}
                  for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
 

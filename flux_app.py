@@ -45,6 +45,11 @@ class SDAPIResponse(BaseModel):
     info: str
 
 
+class RequestFailedOnAllRanks(RuntimeError):
+    """A sharded request failed at a point every rank of the job knows about (agreed through `_all_ok`, or carried in a
+    broadcast header): the ranks are still in step, the server keeps serving."""
+
+
 class FluxAPI:
     """One pipeline cache shared by the HTTP routes and direct callers."""
 
@@ -89,14 +94,51 @@ class FluxAPI:
         encoded images on rank 0, None elsewhere.  A rank that cannot build the pipeline (missing checkpoint ...) must not
         leave the others waiting inside a collective: the outcome of init_pipeline is agreed on first."""
         import torch
+        from flux_generator_amd.parallel import CollectiveStepFailed
         rank, world = _dist_world()
+        if self._desync:
+            raise RuntimeError("the job's ranks are out of step after an earlier failure inside a collective; restart the job")
         err = None
         try:
             pipe = self.init_pipeline(model)
         except Exception as e:                   # noqa: BLE001 - reported to every rank below
             err, pipe = e, None
         if not _all_ok(err is None):
-            raise err if err is not None else RuntimeError("another rank of the job could not build the pipeline")
+            raise RequestFailedOnAllRanks(str(err) if err is not None else "another rank of the job could not build the pipeline")
+        # Fail-stop for the rest of the request.  The ranks meet in collectives at three places: the conditioning broadcast inside
+        # generate_latents (a failure of the rank-0-only text towers travels in the broadcast header and is raised on every rank,
+        # parallel.shard_generation_inputs), nowhere inside the denoise steps or the decode, and the uint8 gather.  A rank-local
+        # failure between two of them (an OOM in a decode ...) would strand the others in the next one, so the outcome of every
+        # rank-local stretch is AGREED ON (`_all_ok`) before the next collective is entered; an exception that is not an agreed
+        # one - raised by a collective itself - leaves the ranks out of step, and then the job stops (`_fatal`).
+        try:
+            out = self._sharded_body(pipe, prompt, model, width, height, steps, guidance, seed, batch_size, n_iter)
+        except (RequestFailedOnAllRanks, CollectiveStepFailed):
+            raise
+        except Exception as e:                   # noqa: BLE001
+            if getattr(e, "_agreed", False):     # raised at the same point on every rank (see _sharded_body)
+                raise RequestFailedOnAllRanks(str(e)) from e
+            self._fatal(e)
+            raise
+        if out is None:
+            return None
+        return self._encode(out, return_pil)
+
+    _desync = False
+
+    def _fatal(self, e) -> None:
+        """An exception out of a collective (timeout, peer gone): the ranks no longer agree on where they are.  Refuse further
+        sharded requests and end this process shortly (the HTTP 500 of the current request still goes out on rank 0); torchrun
+        tears the other ranks down with it."""
+        import os
+        self._desync = True
+        print(f"[flux_app rank {_dist_world()[0]}] fatal: {type(e).__name__}: {e} - leaving the job", file=sys.stderr, flush=True)
+        if _dist_world()[1] > 1 and os.environ.get("FLUX_APP_NO_EXIT") != "1":
+            threading.Timer(1.0, lambda: os._exit(70)).start()
+
+    def _sharded_body(self, pipe, prompt, model, width, height, steps, guidance, seed, batch_size, n_iter):
+        """The request on this rank; returns the list of uint8 images on rank 0, None elsewhere."""
+        import torch
         n = batch_size * n_iter
         latent_size = (height // 8, width // 8)
         sd = model.startswith("stabilityai/")
@@ -111,16 +153,26 @@ class FluxAPI:
                                             guidance=guidance, seed=seed)
             next(latents)                        # conditioning tuple (computed on rank 0, broadcast)
             out_hw = (latent_size[0] * 8, latent_size[1] * 8)
-        x_t = None
-        for x_t in latents:                      # this rank's rows of the batch (pipe.shard); possibly none when n < world
-            pass
-        imgs = [pipe.decode(x_t[i:i + self.DECODE_BATCH]) if sd else pipe.decode(x_t[i:i + self.DECODE_BATCH], latent_size)
-                for i in range(0, len(x_t), self.DECODE_BATCH)]
-        local = torch.cat(imgs, dim=0) if imgs else torch.empty(0, *out_hw, 3, device=x_t.device)
+        err, local = None, None
+        try:                                     # rank-local stretch: denoise steps + decode (no collective inside)
+            x_t = None
+            for x_t in latents:                  # this rank's rows of the batch (pipe.shard); possibly none when n < world
+                pass
+            imgs = [pipe.decode(x_t[i:i + self.DECODE_BATCH]) if sd else pipe.decode(x_t[i:i + self.DECODE_BATCH], latent_size)
+                    for i in range(0, len(x_t), self.DECODE_BATCH)]
+            local = torch.cat(imgs, dim=0) if imgs else torch.empty(0, *out_hw, 3, device=x_t.device)
+            if local.is_cuda:
+                torch.cuda.synchronize(local.device)     # an asynchronous fault of this stretch surfaces here, not inside the gather
+        except Exception as e:                   # noqa: BLE001 - agreed on below
+            err = e
+        if not _all_ok(err is None):             # agreement point in front of the gather
+            e = err if err is not None else RuntimeError("another rank of the job failed in its denoise / decode")
+            e._agreed = True
+            raise e
         allimg = pipe.gather_images(local, n)    # uint8 [n, H, W, 3] on rank 0 (batch order), None elsewhere
         if allimg is None:
             return None
-        return self._encode(list(allimg.cpu().numpy()), return_pil)
+        return list(allimg.cpu().numpy())
 
     @staticmethod
     def _encode(arrs, return_pil):
@@ -238,10 +290,13 @@ def worker_loop(api_: "FluxAPI") -> int:
         req = _bcast_obj(None)
         if req is None:
             return served
+        from flux_generator_amd.parallel import CollectiveStepFailed
         try:
             api_._generate_sharded(**req)
-        except Exception as e:       # noqa: BLE001 - rank 0 reports the failure to the client (HTTP 500); keep serving
+        except (RequestFailedOnAllRanks, CollectiveStepFailed) as e:
+            # failed at an agreed point: rank 0 reports it to the client (HTTP 500), every rank is back at the top of its loop
             print(f"[flux_app worker rank {_dist_world()[0]}] request failed: {e}", file=sys.stderr)
+        # anything else left a collective half-done: _generate_sharded has called _fatal, the exception ends this rank (fail-stop)
         served += 1
 
 
@@ -350,7 +405,11 @@ def main():
             device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
             torch.cuda.set_device(device)
             if not dist.is_initialized():
-                dist.init_process_group("nccl", device_id=torch.device(device))
+                import datetime
+                # explicit collective timeout: a rank that died between two agreement points must not hang its peers for
+                # the backend's default (10-30 min); FLUX_APP_COLLECTIVE_TIMEOUT_S overrides
+                dist.init_process_group("nccl", device_id=torch.device(device),
+                                        timeout=datetime.timedelta(seconds=int(os.environ.get("FLUX_APP_COLLECTIVE_TIMEOUT_S", "300"))))
             if dist.get_rank() != 0:
                 n = worker_loop(api)
                 print(f"[flux_app worker rank {dist.get_rank()}] served {n} requests, exiting")

@@ -79,7 +79,11 @@ DEVINL float gelu_tanh_f(float x) {
 // erfc(|x| / sqrt 2) / 2 below (no 1 + erf cancellation on the negative side).  erfc(z) = t (a1 + t (a2 + ... a5 t)) exp(-z^2),
 // t = 1 / (1 + p z) (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute): 14 VALU instructions incl. one v_rcp_f32 and one
 // v_exp_f32 where libm's erff is ~40 with branches - the GEGLU epilogue of the SDXL UNet is 64 gate elements per lane per tile.
-// The result is rounded to float16 / bfloat16 by the caller (>= 2^-11 relative): the approximation is an order below that.
+// The bound is ABSOLUTE on erfc: the result x * erfc / 2 is right to |x| * 0.75e-7, i.e. below half a float16 / bfloat16 ulp
+// wherever |gelu(x)| >= ~3e-4 and a few ulps of the (tiny) results in the negative tail beyond x ~ -3.7 - relative 2e-3 at x = -4
+// where gelu = -1.3e-4 (tests/test_sd_f16_gpu.py::test_gelu_erf_epilogue_negative_tail_vs_float64 sweeps [-6, 0] against
+// float64).  The reference's float16 evaluation x (1 + erf(x / sqrt 2)) / 2 has no significant bit left there (1 + erf rounds
+// to 0 or 4.9e-4 below x = -3.3), so the tail is closer to the exact function than to anything the reference computes.
 DEVINL float gelu_erf_f(float x) {
   const float z = fabsf(x) * 0.7071067811865476f;
   const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));

@@ -1,6 +1,7 @@
 // Host launchers for the bf16 NT GEMM / implicit-GEMM conv (kernel: gemm_core.h).
 #include "../../include/fluxhip.h"
 #include <cmath>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include "gemm_core.h"
@@ -184,6 +185,11 @@ TileCfg kCfgs[] = {
     make_cfg_f8<256, 160, 4, 2, 2, 6>(),     // 54: 256x160, ping-pong
     with_pair<128, 256, 2, 4, 2, 6>(make_cfg_x3_f8<128, 256, 2, 4, 2, 6>()),     // 55: 128x256, ping-pong
     with_rs<256, 192, 4, 2, 2, 6, 1>(make_cfg<256, 192, 4, 2, 2, 6, 1>()),        // 56: cfg 51 with stamps around the main loop, the split-K reduce-scatter segments and the epilogue (diagnostic)
+    // 57 (round 6): 128x160, ping-pong, 8 waves x (32x80).  1280 = 8 x 160: the M = 4096, N = 1280 projections of the SDXL transformer
+    // blocks (313 launches per UNet step) are 32 x 8 = 256 tiles - one full round - where 128x256 gives 160 tiles on 256 CUs
+    with_lean<128, 160, 4, 2, 2, 6, EPI_GATE_RES>(make_cfg<128, 160, 4, 2, 2, 6>()),
+    make_cfg<128, 160, 4, 2, 3, 5>(),     // 58: 128x160 with a 3 + 4 ring (128 KiB), spread LDS-DMA + fragment reads: two K-steps of loads in flight
+    make_cfg<128, 160, 4, 2, 4, 1>(),     // 59: 128x160, 4-deep plain ring (144 KiB)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -229,9 +235,11 @@ bool g_attr_set[kNumCfgs][14] = {};
 unsigned long long* g_trace = nullptr;   // fluxhip_gemm_set_trace
 // fluxhip_conv_set_x3_tile: forced tile of the fp32-faithful convs (0: the picker; env FLUXHIP_CONV_X3_CFG) and the halo-tile loader
 // (FLAG_DXR; env FLUXHIP_CONV_DXR=0 switches it off) - A/B timing and tests
-int g_conv_x3_cfg = [] { const char* e = getenv("FLUXHIP_CONV_X3_CFG"); return e ? atoi(e) : 0; }();
-bool g_conv_dxr = [] { const char* e = getenv("FLUXHIP_CONV_DXR"); return !(e && e[0] == '0'); }();
-long long g_conv_dxr_launches = 0;
+// (atomics: ctypes callers may launch from several host threads - the GIL is released during a call)
+std::atomic<int> g_conv_x3_cfg{[] { const char* e = getenv("FLUXHIP_CONV_X3_CFG"); return e ? atoi(e) : 0; }()};
+std::atomic<bool> g_conv_dxr{[] { const char* e = getenv("FLUXHIP_CONV_DXR"); return !(e && e[0] == '0'); }()};
+std::atomic<long long> g_conv_dxr_launches{0};
+std::once_flag g_dxr_attr_once[2];        // LDS-size attribute of the two halo-tile kernels: set once, like g_attr_set for the table
 
 // Tile choice: a time model per tile, fitted to tools/gemm_tune.py sweeps.
 //   time = t_launch + R(x) * g(x) * (K/64 * t_step + t_fixed),   x = tiles / (256 CUs x blocks/CU)
@@ -255,6 +263,7 @@ const Cand kCands[] = {
     {54, 1, 1.223f, 8.38f, 0.62f},    // 256x160  "
     {46, 1, 1.023f, 7.18f, 0.62f},    // 256x128, spread LDS-DMA + fragment reads, 3 + 4 ring
     {55, 1, 0.990f, 5.06f, 0.68f},    // 128x256, ping-pong
+    {57, 1, 0.640f, 4.50f, 0.68f},    // 128x160, ping-pong (round 6; provisional until tools/gemm_tune.py has swept it)
     {47, 1, 0.606f, 3.69f, 0.69f},    // 128x128, 8 waves, spread reads
     // two blocks per CU (per-step time with both blocks resident)
     {7, 2, 1.244f, 5.95f, 0.63f},     // 128x128, 4 waves
@@ -459,14 +468,14 @@ int pick_cfg(const int* group_m, int ngroups, int nbatch, int N, int K, bool con
 // mx (fp8 only): 0 = per-token activation scales; 1 = block-scaled activation operand (FLAG_MXA); 2 = e4m3 + block-scale output (FLAG_MXC)
 int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = false, bool f8 = false, bool f16 = false, int mx = 0) {
   int cfg_idx = cfg_code & 0xff;
-  if (!conv && cfg_idx >= 49 && cfg_idx <= 56) {
+  if (!conv && cfg_idx >= 49 && cfg_idx <= 57) {
     // the ping-pong tiles address their dense operands as scalar base + 32-bit byte offset per (group, batch); an
     // operand of 4 GiB or more (no product shape comes near: 65536 x 5120 bf16 is 0.67 GB) goes to the plain-ring
     // tile of the same shape (fp8: the 256 x 256 simple ring)
     const long long esz = f8 ? 1 : 2;
     bool ok = (long long)p.N * p.K * esz < (1ll << 32);
     for (int g = 0; g < p.ngroups; ++g) ok = ok && (long long)p.g[g].M * p.lda * esz < (1ll << 32);
-    static const int plain[8] = {15, 18, 19, 10, 7, 23, 14, 19};   // 49..56 -> same tile shape, PIPE 1 (53: 128 x 128 is cfg 7)
+    static const int plain[9] = {15, 18, 19, 10, 7, 23, 14, 19, 7};   // 49..57 -> same tile shape, PIPE 1 (53: 128 x 128 is cfg 7; 57: 128 x 160 has no plain twin, 128 x 128)
     if (!ok) cfg_idx = f8 ? 6 : (x3 && cfg_idx != 49 ? 15 : plain[cfg_idx - 49]);
   }
   int splits = cfg_code >> 8;
@@ -566,8 +575,12 @@ int launch(GemmParams& p, int cfg_code, bool conv, hipStream_t s, bool x3 = fals
     void (*const dk)(const GemmParams) = g_trace ? gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_DXR | FLAG_TIMED>
                                                  : gemm_nt_kernel<256, 128, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_DXR>;
     lds = 2 * 33 * 1024 + 3 * c.bn * 128;       // two halo slots of 264 rows + the weight ring
-    ++g_conv_dxr_launches;
-    if (hipFuncSetAttribute((const void*)dk, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return FLUXHIP_ELAUNCH;
+    g_conv_dxr_launches.fetch_add(1, std::memory_order_relaxed);
+    bool attr_ok = true;
+    std::call_once(g_dxr_attr_once[g_trace ? 1 : 0], [&] {
+      attr_ok = hipFuncSetAttribute((const void*)dk, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    });
+    if (!attr_ok) return FLUXHIP_ELAUNCH;
     fn = dk;
   } else if (conv && x3 && g_trace && (cfg_idx == 49 || cfg_idx == 52)) {      // diagnostic: the stamped twin of the fp32-faithful conv tile
     void (*const tk)(const GemmParams) = cfg_idx == 49 ? gemm_nt_kernel<256, 256, 4, 2, 1, 2, 6, FLAG_SPLIT | FLAG_TIMED>

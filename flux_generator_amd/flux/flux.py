@@ -209,6 +209,8 @@ class FluxPipeline:
         timesteps = self.sampler.timesteps(num_steps, x_t.shape[1], start=start, stop=stop)
         mods = None
         if self.use_graph and 0 < B <= 2 and num_steps > 1:
+            # (round 6: these launches on a side stream under the PREVIOUS image's VAE decode - HBM-bound GEMV beside MFMA-bound
+            #  convs - measured 0.2 ms per image SLOWER, profiles/r06_negative_experiments.json; they stay in line)
             mods = self.flow.modulation_tables(timesteps[:num_steps], vec, guidance)
         for i in range(num_steps):
             t, t_prev = timesteps[i], timesteps[i + 1]
@@ -328,12 +330,22 @@ class FluxPipeline:
             if not fuse:
                 import warnings
                 warnings.warn("load_adapter: the flow model runs the fp8 plan - the adapter is folded into the weights")
-            return self.flow.fuse_lora(weights, scale=1.0)      # LoRALinear.from_base default scale (flux/lora.py:15)
+            n = self.flow.fuse_lora(weights, scale=1.0)         # LoRALinear.from_base default scale (flux/lora.py:15)
+            self.adapter_layers = dict(branches=0, folded=n)
+            return n
         # The reference wraps EVERY nn.Linear of a block (linear_to_lora_layers, flux/flux.py:229-239), the modulation Linears
         # included, and dreambooth.py saves them all.  Block Linears keep their separate low-rank branch; the modulation
         # Linears are rows of the one concatenated GEMV table evaluated once per image, so their update is folded into the
         # table (bf16, like LoRALinear.fuse) - the only deviation from the unfused reference, of the size of one bf16 rounding
         # of those weights.
+        if self.flow._lora:
+            # a second unfused adapter: `attach_lora` REPLACES the block branches while the first adapter's modulation deltas
+            # are already folded into the table - the two would be mixed silently.  The first adapter's branches are folded
+            # into the weights first (what its modulation half already is), so both adapters apply in full.
+            import warnings
+            warnings.warn(f"load_adapter: folding the {len(self.flow._lora)} branches of the adapter already attached before "
+                          "attaching the next one")
+            self.flow.fuse_attached_lora()
         branch, fold = self.flow.splits_for_adapter(weights)
         n = self.flow.fuse_lora(fold, scale=1.0) if fold else 0
         self.adapter_layers = dict(branches=len(branch) // 2, folded=n)

@@ -78,6 +78,16 @@ class Flux:
         self._w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._lora: Dict[str, Tuple[torch.Tensor, torch.Tensor, float]] = {}   # attach_lora(): layer -> (A^T pad, B^T pad, scale)
         self._lora_zero: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+        # test knob (tests/test_full_size_parity_gpu.py mutation check): (layer name, d) adds d to every E8M0 block-scale byte
+        # right after that layer's block-scaled PRODUCER launch, i.e. the consumer of its output sees scales 2^d too large.
+        # None in the product; set through `set_debug_mx_shift` (rebuilds the launch plans).
+        self.debug_mx_shift: Optional[Tuple[str, int]] = None
+
+    def set_debug_mx_shift(self, layer: Optional[str], shift: int = 1) -> "Flux":
+        self.debug_mx_shift = None if layer is None else (layer, int(shift))
+        self._ws.clear()
+        self.plan_epoch += 1
+        return self
 
     # ------------------------------------------------------------------ parameters
     def _alloc_parameters(self) -> None:
@@ -519,6 +529,9 @@ class Flux:
                 mxd = ops.make_fp8_mx(a_mx=ptr["amx"], a_row0=rows, a_bstride=T, a_kstride=B * T)
             keep.extend([d, sc, mxd])
             call(lib.fluxhip_gemm_fp8_mx, ctypes.byref(d), ctypes.byref(sc), ctypes.byref(mxd))
+            if produce and self.debug_mx_shift is not None and self.debug_mx_shift[0] in wnames:
+                amx, dshift = ws["amx"], self.debug_mx_shift[1]
+                plan.append(("py", lambda: amx.add_(dshift)))      # (mutation knob: never set in the product)
 
         def small(x, wn, out, K, N, silu_in, accum):
             call(lib.fluxhip_small_linear_bf16, x, w(wn + ".weight"), wo(wn + ".bias"), out, B, N, K, silu_in, accum)
@@ -718,23 +731,35 @@ class Flux:
         self.run_plan(ws)
         return ws["pred"].clone()
 
-    def profile_plan(self, ws: dict, with_shape: bool = False) -> list:
+    def profile_plan(self, ws: dict, with_shape: bool = False, with_bytes: bool = False) -> list:
         """Run the plan eagerly with a HIP event pair around every launch (events are recorded on the
         stream the kernels are launched on).  Returns [(kernel label, ms, flops)] in launch order;
-        GEMM labels carry the tile configuration the library selected."""
+        GEMM labels carry the tile configuration the library selected.  with_bytes: a fourth field, the launch's
+        algorithmic HBM bytes (bf16 GEMMs only, 0 elsewhere)."""
         lib = _lib.load()
         stream = torch.cuda.current_stream()
         recs = []
         for fn, args in ws["plan"]:
             if fn in ("keepalive", "join", "mod_end"):
                 continue
+            if fn == "py":
+                args()
+                continue
             if fn == "side":        # timed in line here (the graph runs it on the side stream)
                 fn, args = args
-            label, flops = fn.__name__, 0.0
+            label, flops, nbytes = fn.__name__, 0.0, 0.0
             if fn.__name__ == "fluxhip_gemm_bf16":
                 d = args[0]._obj
                 m_total = sum(d.g[i].M for i in range(d.ngroups)) * d.nbatch
                 flops = 2.0 * m_total * d.N * d.K
+                # algorithmic HBM bytes of the launch (SURVEY.md 8(d)): every operand once - activations, one weight panel per
+                # group, the output, and the residual / gate / bias the epilogue reads
+                nbytes = 2.0 * (m_total * d.K + d.ngroups * d.N * d.K + m_total * d.N + d.ngroups * d.N)
+                for i in range(d.ngroups):
+                    if d.g[i].res:
+                        nbytes += 2.0 * d.g[i].M * d.nbatch * d.N
+                    if d.g[i].gate:
+                        nbytes += 2.0 * d.nbatch * d.N
                 code = lib.fluxhip_gemm_tile_cfg(args[0])      # tile cfg | split-K factor << 8
                 label = f"fluxhip_gemm_bf16/cfg{code & 255}" + (f"s{code >> 8}" if (code >> 8) > 1 else "")
                 if with_shape:
@@ -760,9 +785,11 @@ class Flux:
             e1.record(stream)
             if rc != 0:
                 raise FluxHipError(f"{fn.__name__} failed with code {rc}")
-            recs.append((label, e0, e1, flops))
+            recs.append((label, e0, e1, flops, nbytes))
         torch.cuda.synchronize()
-        return [(l, e0.elapsed_time(e1), f) for l, e0, e1, f in recs]
+        if with_bytes:
+            return [(l, e0.elapsed_time(e1), f, nb) for l, e0, e1, f, nb in recs]
+        return [(l, e0.elapsed_time(e1), f) for l, e0, e1, f, nb in recs]
 
     def run_plan(self, ws: dict, skip_mod: bool = False) -> None:
         """Enqueue the launches of one forward on the current stream.  skip_mod: ws["mods"] already holds this step's
@@ -775,6 +802,9 @@ class Flux:
                 skipping = False
                 continue
             if skipping or fn == "keepalive":
+                continue
+            if fn == "py":          # debug_mx_shift only: a torch op on the current stream
+                args()
                 continue
             if fn == "side":        # fork: launch on the side stream, ordered after everything enqueued so far
                 if self._side is None:

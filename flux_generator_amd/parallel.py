@@ -20,6 +20,22 @@ import torch
 import torch.distributed as dist
 
 
+class CollectiveStepFailed(RuntimeError):
+    """Raised on EVERY rank when a rank-local step in front of a collective failed on one rank (the failing rank raises its
+    own exception): all ranks leave the collective sequence at the same point, so the process group stays usable."""
+
+
+def all_ok(ok: bool) -> bool:
+    """True iff every rank reports ok (one 4-byte all-reduce) - the agreement point in front of a collective whose
+    participants could otherwise diverge.  Without a process group: `ok`."""
+    if not active():
+        return bool(ok)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(t)
+    return int(t.item()) == 0
+
+
 def world() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -128,13 +144,24 @@ def shard_generation_inputs(n_images: int, latent_shape, seed: Optional[int], de
     lo, hi = shard_range(n_images, rank, W)
     txt = vec = None
     meta = torch.zeros(5, dtype=torch.int64, device=device)
+    err = None
     if rank == src:
-        txt, vec = make_conditioning()
-        txt, vec = txt.to(device=device, dtype=dtype).contiguous(), vec.to(device=device, dtype=dtype).contiguous()
-        meta = torch.tensor([*txt.shape, *vec.shape], dtype=torch.int64, device=device)
+        # a failure of the rank-`src`-only text conditioning (missing checkpoint, OOM in T5 ...) must reach EVERY rank: the others
+        # are about to enter the broadcast below and would wait in it for ever.  The header carries the outcome (-1 = failed).
+        try:
+            txt, vec = make_conditioning()
+            txt, vec = txt.to(device=device, dtype=dtype).contiguous(), vec.to(device=device, dtype=dtype).contiguous()
+            meta = torch.tensor([*txt.shape, *vec.shape], dtype=torch.int64, device=device)
+        except Exception as e:                   # noqa: BLE001 - re-raised below, on every rank
+            if not active():
+                raise
+            err = e
+            meta = torch.full((5,), -1, dtype=torch.int64, device=device)
     if active():
         _broadcast(meta, src)
     m = [int(v) for v in meta.tolist()]
+    if m[0] < 0:
+        raise CollectiveStepFailed(f"text conditioning failed on rank {src}" + (f": {type(err).__name__}: {err}" if err else "")) from err
     txt, vec = broadcast_conditioning(txt, vec, shapes=(tuple(m[:3]), tuple(m[3:])), src=src, device=device, dtype=dtype)
     if txt.shape[0] == 1:
         txt, vec = txt.expand(hi - lo, -1, -1).contiguous(), vec.expand(hi - lo, -1).contiguous()
@@ -200,16 +227,23 @@ def broadcast_from(make, device, src: int = 0):
     MAXT, MAXD = 8, 6
     hdr = torch.zeros(1 + MAXT * (2 + MAXD), dtype=torch.int64, device=device)
     ts = None
+    err = None
     if rank == src:
-        ts = [t.to(device).contiguous() for t in make()]
-        if len(ts) > MAXT or any(t.dim() > MAXD for t in ts):
-            raise ValueError("broadcast_from: at most 8 tensors of at most 6 dims")
-        h = [len(ts)]
-        for t in ts:
-            h += [_DTYPES.index(t.dtype), t.dim()] + list(t.shape) + [0] * (MAXD - t.dim())
-        hdr[: len(h)] = torch.tensor(h, dtype=torch.int64)
+        try:                                      # (a failure here is broadcast in the header: see shard_generation_inputs)
+            ts = [t.to(device).contiguous() for t in make()]
+            if len(ts) > MAXT or any(t.dim() > MAXD for t in ts):
+                raise ValueError("broadcast_from: at most 8 tensors of at most 6 dims")
+            h = [len(ts)]
+            for t in ts:
+                h += [_DTYPES.index(t.dtype), t.dim()] + list(t.shape) + [0] * (MAXD - t.dim())
+            hdr[: len(h)] = torch.tensor(h, dtype=torch.int64)
+        except Exception as e:                    # noqa: BLE001 - re-raised below, on every rank
+            err = e
+            hdr[0] = -1
     _broadcast(hdr, src)
     h = [int(v) for v in hdr.tolist()]
+    if h[0] < 0:
+        raise CollectiveStepFailed(f"broadcast_from: the producer failed on rank {src}" + (f": {type(err).__name__}: {err}" if err else "")) from err
     if rank != src:
         ts = []
         for i in range(h[0]):

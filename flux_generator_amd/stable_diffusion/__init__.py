@@ -46,10 +46,16 @@ class StableDiffusion:
         # FLUXHIP_SD_STORAGE=bfloat16): same kernels, float32 range, 8-bit significand, rel-L2 7e-3 against float32 on the
         # full-size UNet where float16 measures ~1e-3.  The VAE decode is float32-faithful either way.
         import os
-        storage = storage or os.environ.get("FLUXHIP_SD_STORAGE")
         if float16:
+            # an explicit float16=True wins over the FLUXHIP_SD_STORAGE environment default (flux_app.py always passes it: the
+            # server must keep building its pipelines with that variable exported); only an explicit storage= can contradict it
             if storage not in (None, "float16"):
                 raise ValueError(f"float16=True stores IEEE half; storage='{storage}' contradicts it")
+            storage = "float16"
+        else:
+            storage = storage or os.environ.get("FLUXHIP_SD_STORAGE")
+        if float16:
+            pass
         elif storage != "bfloat16":
             raise NotImplementedError(
                 "StableDiffusion(float16=False) is the reference's float32 UNet / text-encoder arithmetic "

@@ -152,6 +152,8 @@ class UNetModel:
         self._params = {k: torch.empty(*shp, dtype=self.dtype, device=self.device)
                         for k, shp in unet_weight_shapes(config).items()}
         self._fused: Dict[str, torch.Tensor] = {}
+        self._side = None
+        self._vt_fork = os.environ.get("FLUXHIP_UNET_VT_FORK", "0") == "1"
         self.down, self.up = block_plan(config)
         self._sig_t = sinusoidal_sigmas(config.block_out_channels[0]).to(self.device)
         self._sig_add = (sinusoidal_sigmas(config.addition_time_embed_dim).to(self.device)
@@ -282,13 +284,25 @@ class UNetModel:
         f16 = self.dtype == torch.float16
         o = torch.empty(B, N, C, dtype=self.dtype, device=dev)
         if kv is None:
-            qk = ops.linear(n, self._fused[f"{p}.qk"])                       # [B,N,2C]
             Tkpad = (N + 63) // 64 * 64
             vt = torch.zeros(B, C, Tkpad, dtype=self.dtype, device=dev) if Tkpad != N else torch.empty(B, C, N, dtype=self.dtype, device=dev)
-            # V^T[b] = Wv n[b]^T : A = Wv (shared), "W" operand = the rows of batch b
-            ops.gemm(make_gemm_desc([dict(A=W[f"{p}.value_proj.weight"].data_ptr(), W=n.data_ptr(), C=vt.data_ptr(),
-                                          a_bstride=0, w_bstride=N * C, c_bstride=C * Tkpad, M=C)],
-                                    B, N, C, C, Tkpad), f16)
+            # The [q;k] projection and V^T = Wv n^T read the same LayerNorm output and nothing of each other: with
+            # FLUXHIP_UNET_VT_FORK=1 the V^T GEMM is forked onto a side stream (a parallel branch of the captured step graph) and
+            # joined in front of the attention, so that its 160 tiles run beside the [q;k] launch's partial second round
+            cur = torch.cuda.current_stream()
+            fork = self._vt_fork and B * N >= 2048
+            if fork:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side if fork else cur):
+                # V^T[b] = Wv n[b]^T : A = Wv (shared), "W" operand = the rows of batch b
+                ops.gemm(make_gemm_desc([dict(A=W[f"{p}.value_proj.weight"].data_ptr(), W=n.data_ptr(), C=vt.data_ptr(),
+                                              a_bstride=0, w_bstride=N * C, c_bstride=C * Tkpad, M=C)],
+                                        B, N, C, C, Tkpad), f16)
+            qk = ops.linear(n, self._fused[f"{p}.qk"])                       # [B,N,2C]
+            if fork:
+                cur.wait_stream(self._side)
             ops.attention_strided(qk, qk[..., C:], vt, o, B, H, 64, N, Tk, Tkpad, (N * 2 * C, 64, 2 * C), (N * 2 * C, 64, 2 * C), C,
                                   64 ** -0.5)
         else:

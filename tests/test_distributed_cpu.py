@@ -341,3 +341,77 @@ def test_http_surface_shards_a_request_over_two_ranks():
     assert got == [True, True, True], got
     assert served1 == 2, "the worker rank must have served both requests and left its loop on shutdown"
     assert cond0 == 2 and cond1 == 0, "text conditioning is computed on rank 0 only"
+
+
+# ------------------------------------------------------------------------------------------ sharded HTTP surface: fail-stop
+class _FaultyFlux(_StubFlux):
+    """_StubFlux with injected rank-local failures: `fail_cond` (rank 0's text conditioning raises), `fail_decode` (this rank's
+    decode raises) - armed per request through the prompt text so both ranks see the same schedule."""
+
+    def generate_latents(self, prompt, n_images=1, num_steps=2, latent_size=(8, 8), guidance=4.0, seed=None):
+        from flux_generator_amd import parallel as P
+
+        def cond():
+            self.cond_calls += 1
+            if "bad-prompt" in prompt:
+                raise ValueError("tokenizer exploded")
+            g = torch.Generator().manual_seed(len(prompt))
+            return torch.randn(1, 6, 16, generator=g), torch.randn(1, 8, generator=g)
+
+        x, txt, vec, self.shard = P.shard_generation_inputs(n_images, (*latent_size, 16), seed, "cpu", cond)
+        self._prompt = prompt
+        yield (x, None, txt, None, vec)
+        for _ in range(num_steps):
+            x = (x.float() * 0.5).to(x.dtype)
+            yield x
+
+    def decode(self, x, latent_size):
+        if f"decode-fails-on-{self.rank}" in self._prompt:
+            raise MemoryError("decode ran out of memory")
+        return super().decode(x, latent_size)
+
+
+def _worker_http_faults(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FLUX_APP_NO_EXIT="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import flux_app
+    stub = _FaultyFlux(rank)
+    flux_app.api.init_pipeline = lambda model: stub                # noqa: E731
+    if rank != 0:
+        served = flux_app.worker_loop(flux_app.api)
+        q.put((rank, served, None))
+    else:
+        from fastapi.testclient import TestClient
+        client = TestClient(flux_app.get_app())
+        codes = []
+        for prompt in ("bad-prompt", "decode-fails-on-1", "decode-fails-on-0", "a cat"):
+            r = client.post("/sdapi/v1/txt2img", json=dict(prompt=prompt, width=64, height=64, steps=2, batch_size=2, seed=3,
+                                                           model="schnell"))
+            codes.append((r.status_code, r.json().get("detail", "") if r.status_code != 200 else len(r.json()["images"])))
+        flux_app.shutdown_workers()
+        q.put((rank, 4, codes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_http_surface_rank_local_failures_do_not_strand_the_peers():
+    """Advisor (round 5), flux_app.py: after the agreed `init_pipeline`, a failure on ONE rank - rank 0's text conditioning, any
+    rank's decode - left the other ranks inside the next collective.  Now the conditioning outcome travels in the broadcast
+    header (parallel.shard_generation_inputs) and the denoise / decode stretch is agreed on in front of the gather: every such
+    request is an HTTP 500 on rank 0, the worker is back in its loop, and the NEXT request is served by both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_http_faults, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, _, codes), (_, served1, _) = res
+    assert [c for c, _ in codes] == [500, 500, 500, 200], codes
+    assert "tokenizer exploded" in codes[0][1] and "another rank" in codes[1][1] and "out of memory" in codes[2][1], codes
+    assert codes[3][1] == 2
+    assert served1 == 4, "the worker rank must have gone through all four requests and left its loop on shutdown"

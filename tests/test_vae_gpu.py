@@ -265,6 +265,27 @@ def test_groupnorm_x3(dev, C, hw, silu):
     assert rel_l2(y, ref.float()) < X3
 
 
+def test_groupnorm_silu_x3_elementwise_bound(dev):
+    """The fp32-faithful GroupNorm + SiLU evaluates the sigmoid as rcp(1 + exp2(-y log2 e)) on v_exp_f32 / v_rcp_f32 (1 ulp
+    each; round 5, groupnorm.hip) instead of libm expf + an IEEE division.  Bound of that change (advisor, round 5): every
+    ELEMENT against a float64 evaluation on exactly the input the kernel sees (the hi + lo planes joined: 16 significand bits),
+    so that what is left is the kernel's own arithmetic and the 2^-17 rounding of its output planes:
+    |err| <= 2e-5 |ref| + 2e-6 * max|ref|  (float32 cancellation in (x - mean) near the zeros of the output is absolute)."""
+    from flux_generator_amd import ops
+    C, hw = 256, (32, 32)
+    x = frnd(2, *hw, C, seed=11, scale=3.0) - 0.4                    # normalised values reach |y| ~ 5: both sigmoid tails
+    gam, bet = 1 + 0.3 * frnd(C, seed=12), frnd(C, seed=13, scale=0.3)
+    xs = ops.split_f32(x.to(dev))
+    seen = ops.join_f32(xs).double().cpu()                           # what the planes hold
+    y = ops.join_f32(ops.groupnorm_silu_x3(xs, gam.to(dev), bet.to(dev), 32, 1e-6, True)).double().cpu()
+    ref = O.silu(O.group_norm(seen, gam.double(), bet.double(), 32, 1e-6))
+    err = (y - ref).abs()
+    bound = 2e-5 * ref.abs() + 2e-6 * float(ref.abs().max())
+    print(f"groupnorm+silu x3: max |err| {float(err.max()):.2e}, max err / bound {float((err / bound).max()):.2f}, "
+          f"max relative error where |ref| > 0.1: {float((err / ref.abs())[ref.abs() > 0.1].max()):.2e} (output planes resolve 7.6e-6)")
+    assert bool((err <= bound).all())
+
+
 def test_small_ops_x3(dev):
     from flux_generator_amd import ops
     # conv_out 128 -> 3 with float32 weights on a split input

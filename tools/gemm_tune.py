@@ -8,7 +8,7 @@ import torch
 from flux_generator_amd import ops, _lib
 
 dev = torch.device("cuda:0")
-BF = torch.bfloat16
+BF = torch.float16 if os.environ.get("TUNE_F16") else torch.bfloat16      # TUNE_F16=1: the float16-storage kernels (SD / SDXL UNet)
 lib = _lib.load()
 ncfg = 0
 import ctypes

@@ -14,7 +14,9 @@ Inputs are regenerated from their seeds by the tests; nothing under /root/refere
 Also here (moved out of tests/ in round 5 so that the default GPU suite has no skipped tests): the diagnostic
 `which rounding compounds` run of round 4 (fp32 oracle with only the residual stream rounded to bf16 between blocks).
 
-usage (GPU box):  python tools/make_full_size_golden.py [c4] [c3] [c5] [rounding]      (default: c4 c3 c5)
+usage (GPU box):  python tools/make_full_size_golden.py [c4] [c3] [c5] [c3live] [c5live] [rounding]      (default: c4 c3 c5)
+(`c3live` / `c5live`, round 6: the same cases with O(0.3) modulation - tests/full_size_cases.py - and, for c5, the measured
+effect of the committed mutation: one layer's E8M0 block scales shifted by one exponent)
 Writes tests/golden/full_size/<case>.pt and gpurun_out/full_size_golden/<case>.pt + summary.json (gpurun merges the latter
 back; copy the .pt files into tests/golden/full_size/ and commit them)."""
 import json
@@ -70,8 +72,8 @@ def oracle_flux(OP, W, inputs, t, guidance=None, dtype=torch.float32):
     return torch.cat(outs, 0), time.perf_counter() - t0
 
 
-def make_c3(dev):
-    case = FC.c3_case(dev)
+def make_c3(dev, live=False):
+    case = FC.c3_case(dev, live=live)
     P = case["P"]
     OP = O.FluxParams(**{k: getattr(P, k) for k in O.FluxParams.__dataclass_fields__})
     got = FC.c3_forward(case, dev)
@@ -79,15 +81,18 @@ def make_c3(dev):
     ref16, secs16 = oracle_flux(OP, device_weights(case["flow"].parameters(), dtype=BF), case["inputs"], case["t"], case["guidance"], dtype=BF)
     m = dict(hip_vs_fp32=rel_l2(got, ref), hip_vs_bf16_oracle=rel_l2(got, ref16), bf16_oracle_vs_fp32=rel_l2(ref16, ref),
              oracle_seconds=secs, oracle_bf16_seconds=secs16, host_threads=torch.get_num_threads())
-    print("c3", m, flush=True)
-    SUMMARY["c3"] = m
-    save("c3_dev_t4608.pt", dict(ref_fp32=ref.to(torch.float16), ref_bf16=ref16.to(BF), weight_hash=case["hash"], measured=m,
-                                 meta="Flux-dev init_random(4), inputs seed 2, S=512 L=4096, t=timesteps(28)[1], guidance 7; "
-                                      "ref_fp32 = fp32 oracle (stored float16), ref_bf16 = oracle in the reference's bf16 arithmetic"))
+    tag = "c3_live" if live else "c3"
+    print(tag, m, flush=True)
+    SUMMARY[tag] = m
+    save("c3_dev_t4608_live.pt" if live else "c3_dev_t4608.pt",
+         dict(ref_fp32=ref.to(torch.float16), ref_bf16=ref16.to(BF), weight_hash=case["hash"], measured=m,
+              meta="Flux-dev init_random(4)" + (" + modulation biases U(-0.5, 0.5) (live_modulation seed 14)" if live else "") +
+                   ", inputs seed 2, S=512 L=4096, t=timesteps(28)[1], guidance 7; "
+                   "ref_fp32 = fp32 oracle (stored float16), ref_bf16 = oracle in the reference's bf16 arithmetic"))
 
 
-def make_c5(dev):
-    case = FC.c5_case(dev)
+def make_c5(dev, live=False):
+    case = FC.c5_case(dev, live=live)
     P = case["P"]
     flow = case["flow"]
     OP = O.FluxParams(**{k: getattr(P, k) for k in O.FluxParams.__dataclass_fields__})
@@ -98,11 +103,21 @@ def make_c5(dev):
     ref, secs = oracle_flux(OP, device_weights(flow.parameters(), dequant=flow._w8), case["inputs"], case["t"])
     m = dict(fp8_vs_dequant_fp32=rel_l2(got, ref), bf16_plan_vs_dequant_fp32=rel_l2(got16, ref), fp8_vs_bf16_plan=rel_l2(got, got16),
              per_image=[rel_l2(got[i], ref[i]) for i in range(4)], oracle_seconds=secs, host_threads=torch.get_num_threads())
-    print("c5", m, flush=True)
-    SUMMARY["c5"] = m
-    save("c5_fp8_b4_t4352.pt", dict(ref_fp32=ref.to(torch.float16), weight_hash=case["hash"], measured=m,
-                                    meta="Flux-schnell init_random(3) + enable_fp8, inputs seed 6, B=4 S=256 L=4096, t=0.75; "
-                                         "fp32 oracle on the DE-QUANTISED e4m3 weights (stored float16)"))
+    # the mutation the stored vector must be able to see: ONE layer's E8M0 block scales one exponent too large
+    flow.set_debug_mx_shift(FC.C5_MUTATED_LAYER, 1)
+    bad = FC.c5_forward(case, dev)
+    flow.set_debug_mx_shift(None)
+    m["mutated_layer"] = FC.C5_MUTATED_LAYER
+    m["mutated_fp8_vs_dequant_fp32"] = rel_l2(bad, ref)
+    m["mutated_per_image"] = [rel_l2(bad[i], ref[i]) for i in range(4)]
+    tag = "c5_live" if live else "c5"
+    print(tag, m, flush=True)
+    SUMMARY[tag] = m
+    save("c5_fp8_b4_t4352_live.pt" if live else "c5_fp8_b4_t4352.pt",
+         dict(ref_fp32=ref.to(torch.float16), weight_hash=case["hash"], measured=m,
+              meta="Flux-schnell init_random(3)" + (" + modulation biases U(-0.5, 0.5) (live_modulation seed 13)" if live else "") +
+                   " + enable_fp8, inputs seed 6, B=4 S=256 L=4096, t=0.75; "
+                   "fp32 oracle on the DE-QUANTISED e4m3 weights (stored float16)"))
 
 
 def make_c4(dev):
@@ -165,6 +180,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["c4", "c3", "c5"]
     for w in which:
         t0 = time.perf_counter()
-        dict(c3=make_c3, c5=make_c5, c4=make_c4, rounding=make_rounding)[w](dev)
+        dict(c3=make_c3, c5=make_c5, c4=make_c4, rounding=make_rounding, c3live=lambda d: make_c3(d, True),
+             c5live=lambda d: make_c5(d, True))[w](dev)
         torch.cuda.empty_cache()
         print(f"{w}: {time.perf_counter() - t0:.0f} s", flush=True)
