@@ -140,6 +140,16 @@ SIGNATURES = {
     "fluxhip_unpack_latents_x3": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 5 + [c_float, c_float, c_void_p]),
     "fluxhip_pixel_linear_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                         c_float, c_void_p]),
+    # float32 arithmetic of the stable_diffusion/ UNet / CLIP (float16=False) on split tensors (ABI 9)
+    "fluxhip_layernorm_x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
+    "fluxhip_act_x3": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "fluxhip_addvec_x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
+    "fluxhip_sincos_embed_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "fluxhip_axpbypcz_f32": (c_int, [c_void_p] * 4 + [c_int64, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "fluxhip_softmax_rows_masked_x3": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
+    "fluxhip_embedding_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "fluxhip_pixel_linear_x3_f32in": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                              c_float, c_void_p]),
 }
 # float16-storage twins (the stable_diffusion/ models with float16=True): same signatures as the bf16 entry points
 for _b, _f in (("fluxhip_gemm_bf16", "fluxhip_gemm_f16"), ("fluxhip_conv2d_bf16", "fluxhip_conv2d_f16"),
@@ -184,7 +194,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fluxhip_abi_version() != 8 and not ab:
+    if lib.fluxhip_abi_version() != 9 and not ab:
         raise RuntimeError("libfluxhip ABI version mismatch")
     if lib.fluxhip_arch() != b"gfx950":
         raise RuntimeError("libfluxhip was not built for gfx950")

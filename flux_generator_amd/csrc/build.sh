@@ -12,7 +12,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # plain VALU instructions in inline asm, and the formation is switched off for the whole library: a same-box A/B of the two
 # builds measures no difference (22.05 / 21.98 vs 22.09 / 22.01 images/s, denoise step 18.00 / 18.04 vs 18.04 / 18.07 ms).
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -Xclang -target-feature -Xclang -packed-fp32-ops ${FLUXHIP_EXTRA_FLAGS:-}"
-SRCS="api gemm gemm_conv gemm_x3f8 gemm_mx gemm_f16 gemm_conv_f16 small_linear norm groupnorm attention elementwise unet_ops"
+SRCS="api gemm gemm_conv gemm_x3f8 gemm_mx gemm_f16 gemm_conv_f16 small_linear norm groupnorm attention elementwise unet_ops unet_x3"
 pids=()
 for s in $SRCS; do
   if [ ! -f $BUILD/$s.o ] || [ $s.hip -nt $BUILD/$s.o ] || [ common.h -nt $BUILD/$s.o ] || \

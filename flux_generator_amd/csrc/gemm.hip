@@ -188,8 +188,8 @@ TileCfg kCfgs[] = {
     // 57 (round 6): 128x160, ping-pong, 8 waves x (32x80).  1280 = 8 x 160: the M = 4096, N = 1280 projections of the SDXL transformer
     // blocks (313 launches per UNet step) are 32 x 8 = 256 tiles - one full round - where 128x256 gives 160 tiles on 256 CUs
     with_lean<128, 160, 4, 2, 2, 6, EPI_GATE_RES>(make_cfg<128, 160, 4, 2, 2, 6>()),
-    make_cfg<128, 160, 4, 2, 3, 5>(),     // 58: 128x160 with a 3 + 4 ring (128 KiB), spread LDS-DMA + fragment reads: two K-steps of loads in flight
-    make_cfg<128, 160, 4, 2, 4, 1>(),     // 59: 128x160, 4-deep plain ring (144 KiB)
+    // (the same tile with a 3 + 4 ring on the spread schedule and with a 4-deep plain ring were built and swept with it: level
+    //  (620 / 709 / 869 TFLOP/s on the three shapes below) and 8 % slower - the K-step is not waiting for its loads - removed)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -263,7 +263,8 @@ const Cand kCands[] = {
     {54, 1, 1.223f, 8.38f, 0.62f},    // 256x160  "
     {46, 1, 1.023f, 7.18f, 0.62f},    // 256x128, spread LDS-DMA + fragment reads, 3 + 4 ring
     {55, 1, 0.990f, 5.06f, 0.68f},    // 128x256, ping-pong
-    {57, 1, 0.640f, 4.50f, 0.68f},    // 128x160, ping-pong (round 6; provisional until tools/gemm_tune.py has swept it)
+    {57, 1, 0.720f, 5.50f, 0.68f},    // 128x160, ping-pong (round 6; float16 sweep at M = 4096, profiles/r06_gemm_tune_sdxl_f16.txt: N = K = 1280
+                                      //  21.7 us = 619 TFLOP/s where 128x256 takes 23.6; K = 5120 62.0 us = 866 against 75.0)
     {47, 1, 0.606f, 3.69f, 0.69f},    // 128x128, 8 waves, spread reads
     // two blocks per CU (per-step time with both blocks resident)
     {7, 2, 1.244f, 5.95f, 0.63f},     // 128x128, 4 waves

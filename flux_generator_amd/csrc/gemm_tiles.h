@@ -18,8 +18,7 @@
   X(256, 224, 4, 2, 2, 5, 0) X(256, 192, 4, 2, 2, 5, 0) X(256, 128, 4, 2, 3, 5, 0) X(128, 128, 2, 4, 3, 5, 0) \
   X(256, 256, 4, 2, 2, 5, 1) X(256, 256, 4, 2, 2, 6, 0) X(256, 224, 4, 2, 2, 6, 0) X(256, 192, 4, 2, 2, 6, 0) \
   X(256, 128, 4, 2, 2, 6, 0) X(128, 128, 2, 4, 2, 6, 0) X(256, 160, 4, 2, 2, 6, 0) X(128, 256, 2, 4, 2, 6, 0) \
-  X(256, 192, 4, 2, 2, 6, 1) X(128, 160, 4, 2, 2, 6, 0) \
-  X(128, 160, 4, 2, 3, 5, 0) X(128, 160, 4, 2, 4, 1, 0)
+  X(256, 192, 4, 2, 2, 6, 1) X(128, 160, 4, 2, 2, 6, 0)
 
 // tiles that also have fp32-faithful (FLAG_SPLIT) kernels, dense and conv
 #define FLUXHIP_TILES_X3(X)                                                                                   \
@@ -46,8 +45,7 @@
 #define FLUXHIP_TILES_F16_DENSE(X)                                                                            \
   X(256, 256, 4, 2, 2, 6) X(256, 224, 4, 2, 2, 6) X(256, 192, 4, 2, 2, 6) X(256, 160, 4, 2, 2, 6)             \
   X(256, 128, 4, 2, 3, 5) X(128, 256, 2, 4, 2, 6) X(128, 128, 2, 4, 3, 5) X(128, 128, 2, 2, 2, 1)             \
-  X(128, 64, 2, 2, 2, 1) X(64, 128, 2, 2, 2, 1) X(64, 64, 2, 2, 2, 0) X(128, 160, 4, 2, 2, 6) \
-  X(128, 160, 4, 2, 3, 5) X(128, 160, 4, 2, 4, 1)
+  X(128, 64, 2, 2, 2, 1) X(64, 128, 2, 2, 2, 1) X(64, 64, 2, 2, 2, 0) X(128, 160, 4, 2, 2, 6)
 #define FLUXHIP_TILES_F16_CONV(X)                                                                             \
   X(256, 256, 4, 2, 2, 6) X(256, 224, 4, 2, 2, 6) X(256, 192, 4, 2, 2, 6) X(256, 160, 4, 2, 2, 6)             \
   X(256, 128, 4, 2, 2, 1) X(128, 256, 2, 4, 2, 6) X(128, 128, 2, 2, 2, 1) X(128, 64, 2, 2, 2, 1)              \

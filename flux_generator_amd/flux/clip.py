@@ -56,9 +56,13 @@ class CLIPTextModel:
     def __init__(self, config: CLIPTextModelConfig, device: Union[str, torch.device] = "cuda", dtype: torch.dtype = BF16):
         """dtype: 16-bit storage type — torch.bfloat16 (the Flux pipeline's dtype, flux/flux.py:24) or torch.float16 (the
         stable_diffusion/ towers under float16=True, stable_diffusion/.../model_io.py:171-174)."""
-        if dtype not in (BF16, torch.float16):
-            raise ValueError("CLIPTextModel dtype must be torch.bfloat16 or torch.float16")
+        if dtype not in (BF16, torch.float16, torch.float32):
+            raise ValueError("CLIPTextModel dtype must be torch.bfloat16, torch.float16 or torch.float32")
         self.dtype = dtype
+        # torch.float32: the stable_diffusion/ towers under the reference's default float16=False (model_io.py:171-174):
+        # float32 master parameters, the forward on the float32-faithful split-bf16 kernels (`_call_f32`)
+        self.x3 = dtype == torch.float32
+        self._x3: Dict[str, torch.Tensor] = {}
         if config.model_dims // config.num_heads != 64:
             raise ValueError("libfluxhip CLIP attention is built for head_dim 64")
         if config.hidden_act not in _ACT_EPI:
@@ -147,6 +151,14 @@ class CLIPTextModel:
     def finalize(self) -> "CLIPTextModel":
         P = self._params
         self._qk = {}
+        if self.x3:
+            self._x3 = {k: ops.split_f32(w.contiguous()) for k, w in P.items()
+                        if k.endswith(".weight") and w.dim() == 2 and "embedding" not in k}
+            T, D = P["position_embedding.weight"].shape
+            pos = torch.zeros((T + 7) // 8 * 8, D, dtype=torch.float32, device=self.device)     # rows padded with the sequence (see _call_f32)
+            pos[:T] = P["position_embedding.weight"]
+            self._x3["pos"] = pos
+            return self
         was8, self._w8 = getattr(self, "fp8", False), {}
         for i in range(self.config.num_layers):
             a = f"layers.{i}.attention"
@@ -156,8 +168,60 @@ class CLIPTextModel:
             self.enable_fp8(True)
         return self
 
+    def _call_f32(self, x: torch.Tensor) -> CLIPOutput:
+        """`__call__` in float32 arithmetic on split tensors (hi + lo bf16 planes; include/fluxhip.h "ABI 9"): every Linear is
+        fluxhip_gemm_x3, LayerNorm / activation / softmax are float32 kernels, the per-head attention products are H-batched
+        float32-faithful GEMMs with a float32 causal softmax in between (clip.py:127-155).  The sequence is zero-padded to a
+        multiple of 8 tokens (GEMM granularity): under the causal mask no real row sees a padding row, and the padding rows are
+        dropped from every output.  Outputs are float32."""
+        c, P, X = self.config, self._params, self._x3
+        tokens = x.to(dtype=torch.int32)
+        B, N = tokens.shape
+        eos = tokens.argmax(-1)
+        D, H = c.model_dims, c.num_heads
+        Np = (N + 7) // 8 * 8
+        Tpad = (Np + 63) // 64 * 64
+        tok = torch.zeros(B, Np, dtype=torch.int32)
+        tok[:, :N] = tokens
+        tok = tok.to(self.device).contiguous()
+        dev = self.device
+        h = ops.embedding_x3(tok, P["token_embedding.weight"], X["pos"][:Np].contiguous())            # [2,B,Np,D]
+        o = torch.empty(2, B, Np, D, dtype=BF16, device=dev)
+        vt = torch.zeros(2, D, Tpad, dtype=BF16, device=dev)
+        s = torch.empty(H, Np, Tpad, dtype=torch.float32, device=dev)
+        pm = torch.empty(2, H, Np, Tpad, dtype=BF16, device=dev)
+        act = ops.ACT_QUICK_GELU if c.hidden_act == "quick_gelu" else ops.ACT_GELU_ERF
+        hs = []
+        for i in range(c.num_layers):
+            p = f"layers.{i}"
+            a = f"{p}.attention"
+            y = ops.layernorm_x3(h, P[f"{p}.layer_norm1.weight"], P[f"{p}.layer_norm1.bias"])
+            q = ops.linear_x3(y, X[f"{a}.query_proj.weight"], P[f"{a}.query_proj.bias"])
+            k = ops.linear_x3(y, X[f"{a}.key_proj.weight"], P[f"{a}.key_proj.bias"])
+            k_hm = k.view(2, B, Np, H, 64).permute(0, 1, 3, 2, 4).contiguous()                       # [2,B,H,Np,64]: a copy, no arithmetic
+            for b in range(B):
+                ops.gemm_x3_batched(X[f"{a}.value_proj.weight"], y[:, b], vt, D, Np, D, D, Tpad, 1, 0, 0, 0,
+                                    bias=P[f"{a}.value_proj.bias"], row_bias=True)
+                ops.gemm_x3_batched(q[:, b], k_hm[:, b], s, Np, Np, 64, D, Tpad, H, 64, Np * 64, Np * Tpad, out_f32=True)
+                ops.softmax_rows_masked_x3(s, 64 ** -0.5, pm, cols=Np, causal_T=Np)
+                ops.gemm_x3_batched(pm, vt, o[:, b], Np, 64, Tpad, Tpad, D, H, Np * Tpad, 64 * Tpad, 64)
+            h = ops.linear_x3(o, X[f"{a}.out_proj.weight"], P[f"{a}.out_proj.bias"], res=h)
+            y = ops.layernorm_x3(h, P[f"{p}.layer_norm2.weight"], P[f"{p}.layer_norm2.bias"])
+            y = ops.act_x3(ops.linear_x3(y, X[f"{p}.linear1.weight"], P[f"{p}.linear1.bias"]), act)
+            h = ops.linear_x3(y, X[f"{p}.linear2.weight"], P[f"{p}.linear2.bias"], res=h)
+            hs.append(ops.join_f32(h)[:, :N].contiguous())
+        last = ops.layernorm_x3(h, P["final_layer_norm.weight"], P["final_layer_norm.bias"])
+        rows = (torch.arange(B, dtype=torch.int32) * Np + eos.cpu().to(torch.int32)).to(dev).contiguous()
+        pooled = torch.stack([ops.embedding(rows, last[pl].view(B * Np, D)) for pl in (0, 1)])      # [2,B,D]: a gather per plane
+        if c.projection_dim is not None:
+            pooled = ops.linear_x3(pooled, X["text_projection.weight"], None)
+        return CLIPOutput(pooled_output=ops.join_f32(pooled), last_hidden_state=ops.join_f32(last)[:, :N].contiguous(),
+                          hidden_states=hs)
+
     def __call__(self, x: torch.Tensor) -> CLIPOutput:
         """CLIPTextModel.__call__ (flux/clip.py:127-155): tokens [B,N]."""
+        if self.x3:
+            return self._call_f32(x)
         c, P = self.config, self._params
         tokens = x.to(dtype=torch.int32)
         B, N = tokens.shape

@@ -713,6 +713,8 @@ def concat_channels(a: torch.Tensor, b: Optional[torch.Tensor], pad_to: int = 0)
 
 def axpbypcz(x: torch.Tensor, y: torch.Tensor, z: Optional[torch.Tensor], ca: float, cb: float, cc: float = 0.0,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if x.dtype == torch.float32:            # float32 latents (float16=False pipelines)
+        return axpbypcz_f32(x, y, z, ca, cb, cc, out=out)
     f16 = _e16((x, "x"), (y, "y"), (z, "z"), (out, "out"))
     if out is None:
         out = torch.empty_like(x)
@@ -724,6 +726,8 @@ def axpbypcz(x: torch.Tensor, y: torch.Tensor, z: Optional[torch.Tensor], ca: fl
 def axpbypcz_dev(x: torch.Tensor, y: torch.Tensor, z: Optional[torch.Tensor], coef: torch.Tensor,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = coef[0]*x + coef[1]*y + coef[2]*z with coef a float32[3] DEVICE tensor (graph-replayable sampler step)."""
+    if x.dtype == torch.float32:
+        return axpbypcz_f32(x, y, z, coef=coef, out=out)
     f16 = _e16((x, "x"), (y, "y"), (z, "z"), (out, "out"))
     if coef.dtype != torch.float32 or coef.numel() < 3 or not coef.is_cuda:
         raise FluxHipError("coef must be a float32[3] device tensor")
@@ -784,3 +788,129 @@ def embedding(idx: torch.Tensor, table: torch.Tensor, pos: Optional[torch.Tensor
     fn, name = _fn("fluxhip_embedding_bf16", f16)
     _check(fn(_p(idx), _p(table), _p(pos), _p(out), idx.numel(), D, T, table.shape[0], _stream()), name)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ float32 arithmetic (float16=False) of the
+# stable_diffusion/ UNet and text towers: split tensors [2, ...] (hi, lo bf16 planes), include/fluxhip.h "ABI 9"
+ACT_SILU, ACT_GELU_ERF, ACT_QUICK_GELU, ACT_GEGLU = 0, 1, 2, 3
+
+
+def _split_rows_ok(t: torch.Tensor, name: str) -> None:
+    """A split tensor whose planes may be row-strided VIEWS (last dim contiguous)."""
+    if t.dtype != BF16 or t.dim() < 2 or t.shape[0] != 2 or t.stride(-1) != 1 or not t.is_cuda:
+        raise FluxHipError(f"{name} must be a split tensor: bf16 [2, ...] planes with a contiguous last dimension")
+
+
+def layernorm_x3(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], eps: float = 1e-5,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.LayerNorm over the last dim of a split tensor [2, ..., D] in float32 (gamma / beta float32)."""
+    _split_ok(x, "x")
+    D = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    _check(_lib.load().fluxhip_layernorm_x3(_p(x[0]), x.stride(0), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), _p(out[0]),
+                                            out.stride(0), x[0].numel() // D, D, float(eps), _stream()), "fluxhip_layernorm_x3")
+    return out
+
+
+def act_x3(a: torch.Tensor, mode: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Elementwise activation of a split tensor [2, ..., C] in float32; ACT_GEGLU: a is [2, ..., 2C] = [value | gate] and the
+    result [2, ..., C] = value * gelu_erf(gate)."""
+    _split_ok(a, "a")
+    ld = a.shape[-1]
+    cols = ld // 2 if mode == ACT_GEGLU else ld
+    rows = a[0].numel() // ld
+    if out is None:
+        out = torch.empty(2, *a.shape[1:-1], cols, dtype=BF16, device=a.device)
+    _check(_lib.load().fluxhip_act_x3(_p(a[0]), a.stride(0), ld, _p(out[0]), out.stride(0), cols, rows, cols, int(mode),
+                                      cols if mode == ACT_GEGLU else 0, _stream()), "fluxhip_act_x3")
+    return out
+
+
+def addvec_x3(x: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """x [2, B, ..., C] += v [2, B, C] (broadcast over the pixels of image b), in place."""
+    _split_ok(x, "x"); _split_ok(v, "v")
+    B, C = x.shape[1], x.shape[-1]
+    _check(_lib.load().fluxhip_addvec_x3(_p(x[0]), x.stride(0), _p(v[0]), v.stride(0), B, x[0].numel() // (B * C), C, _stream()),
+           "fluxhip_addvec_x3")
+    return x
+
+
+def sincos_embed_x3(x: torch.Tensor, sig: torch.Tensor) -> torch.Tensor:
+    """x float32 [n], sig float32 [half] -> split [2, n, 2 half] = [cos | sin] in float32."""
+    if x.dtype != torch.float32 or sig.dtype != torch.float32:
+        raise FluxHipError("sincos_embed_x3 takes float32 inputs")
+    n, half = x.numel(), sig.numel()
+    out = torch.empty(2, n, 2 * half, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_sincos_embed_x3(_p(x.contiguous()), _p(sig.contiguous()), _p(out[0]), out.stride(0), n, half,
+                                               _stream()), "fluxhip_sincos_embed_x3")
+    return out
+
+
+def axpbypcz_f32(x: torch.Tensor, y: torch.Tensor, z: Optional[torch.Tensor], ca: float = 0.0, cb: float = 0.0, cc: float = 0.0,
+                 coef: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = ca x + cb y + cc z on contiguous float32 tensors; coef: float32[3] device tensor overriding (ca, cb, cc)."""
+    for t, n in ((x, "x"), (y, "y"), (z, "z"), (out, "out")):
+        _f32c(t, n)
+    if coef is not None and (coef.dtype != torch.float32 or coef.numel() < 3 or not coef.is_cuda):
+        raise FluxHipError("coef must be a float32[3] device tensor")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(_lib.load().fluxhip_axpbypcz_f32(_p(x), _p(y), _p(z), _p(out), x.numel(), float(ca), float(cb), float(cc), _p(coef),
+                                            _stream()), "fluxhip_axpbypcz_f32")
+    return out
+
+
+def softmax_rows_masked_x3(s: torch.Tensor, scale: float, out: torch.Tensor, cols: Optional[int] = None, causal_T: int = 0):
+    """s float32 [..., ld] -> split probabilities out [2, ..., ld]: softmax(scale * s[..., :cols]); causal_T > 0: row r of the
+    flattened [..., causal_T, ld] logits sees columns [0, r % causal_T]; every other column is written as zero."""
+    _f32c(s, "s"); _split_ok(out, "out")
+    ld = s.shape[-1]
+    _check(_lib.load().fluxhip_softmax_rows_masked_x3(_p(s), _p(out[0]), out.stride(0), s.numel() // ld, ld if cols is None else cols,
+                                                      ld, float(scale), int(causal_T), _stream()), "fluxhip_softmax_rows_masked_x3")
+    return out
+
+
+def embedding_x3(idx: torch.Tensor, table: torch.Tensor, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """idx int32 [..., T], float32 table [V, D] (+ float32 pos [T, D]) -> split [2, ..., T, D]."""
+    _f32c(table, "table"); _f32c(pos, "pos")
+    if idx.dtype != torch.int32 or not idx.is_contiguous():
+        raise FluxHipError("idx must be contiguous int32")
+    V, D = table.shape
+    out = torch.empty(2, *idx.shape, D, dtype=BF16, device=table.device)
+    _check(_lib.load().fluxhip_embedding_x3(_p(idx), _p(table), _p(pos), _p(out[0]), out.stride(0), idx.numel(), D,
+                                            idx.shape[-1] if pos is not None else 1, V, _stream()), "fluxhip_embedding_x3")
+    return out
+
+
+def pixel_linear_x3_f32in(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], pad_to: int, in_div: float) -> torch.Tensor:
+    """pixel_linear_x3 on float32 latents (float16=False pipelines)."""
+    _f32c(x, "x"); _f32c(w, "w")
+    Cin, Cout = x.shape[-1], w.shape[0]
+    out = torch.empty(2, *x.shape[:-1], pad_to, dtype=BF16, device=x.device)
+    _check(_lib.load().fluxhip_pixel_linear_x3_f32in(_p(x), _p(w), _p(_f32c(b, "bias")), _p(out[0]), out.stride(0), x.numel() // Cin,
+                                                     Cin, Cout, pad_to, float(in_div), _stream()), "fluxhip_pixel_linear_x3_f32in")
+    return out
+
+
+def gemm_x3_batched(A: torch.Tensor, W: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, lda: int, ldc: int, nbatch: int,
+                    a_bstride: int, w_bstride: int, c_bstride: int, bias: Optional[torch.Tensor] = None, row_bias: bool = False,
+                    alpha: float = 1.0, out_f32: bool = False) -> None:
+    """`gemm_x3` over `nbatch` problems that differ by element strides of A / W / C (0 = shared): the per-head products of the
+    float32 multi-head attention - Q_h K_h^T with a_bstride = w_bstride = head_dim (the heads are column blocks of the [T, C]
+    projections), P_h V_h^T with c_bstride = head_dim.  A / W / C may be row-strided views of split tensors."""
+    _split_rows_ok(A, "A"); _split_rows_ok(W, "W")
+    d = GemmX3Desc()
+    d.A, d.W, d.bias, d.res = _p(A[0]), _p(W[0]), _p(_f32c(bias, "bias")), None
+    d.a_lo, d.w_lo = A.stride(0), W.stride(0)
+    if out_f32:
+        if C.dtype != F32 or C.stride(-1) != 1:
+            raise FluxHipError("C must be float32 with a contiguous last dimension")
+        d.C, d.c_lo = _p(C), 0
+    else:
+        _split_rows_ok(C, "C")
+        d.C, d.c_lo = _p(C[0]), C.stride(0)
+    d.M, d.nbatch, d.N, d.K, d.lda, d.ldc = M, nbatch, N, K, lda, ldc
+    d.a_bstride, d.w_bstride, d.c_bstride = a_bstride, w_bstride, c_bstride
+    d.epi, d.row_bias, d.out_f32, d.tile_cfg, d.alpha = EPI_BIAS, int(row_bias), int(out_f32), 0, alpha
+    _check(_lib.load().fluxhip_gemm_x3(d, _stream()), "fluxhip_gemm_x3")

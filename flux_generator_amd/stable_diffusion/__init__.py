@@ -38,40 +38,37 @@ class StableDiffusion:
 
     def __init__(self, model: str = _DEFAULT_MODEL, float16: bool = False, device: str = "cuda", use_graph: bool = True,
                  storage: Optional[str] = None):
-        # float16=True is the reference's float16 arithmetic (__init__.py:20-27; flux_app.py:77-79 passes it): UNet and text
+        # float16=True: the reference's float16 arithmetic (__init__.py:20-27; flux_app.py:77-79 passes it) - UNet and text
         # towers store IEEE half and multiply on v_mfma_f32_16x16x32_f16 with fp32 accumulate / norms / softmax.
-        # float16=False asks for the reference's FLOAT32 UNet / CLIP (__init__.py:18-23).  That arithmetic is not built here
-        # (the float32-faithful split-bf16 kernels cover the VAE decoders only), and a narrower one is not substituted
-        # silently: the constructor raises unless the caller opts into bfloat16 STORAGE by name - storage="bfloat16" (or
-        # FLUXHIP_SD_STORAGE=bfloat16): same kernels, float32 range, 8-bit significand, rel-L2 7e-3 against float32 on the
-        # full-size UNet where float16 measures ~1e-3.  The VAE decode is float32-faithful either way.
+        # float16=False (the reference's DEFAULT): its FLOAT32 UNet / CLIP (__init__.py:18-23).  Round 6: that arithmetic is built -
+        # float32 master parameters, every Linear / conv on the float32-faithful split-bf16 kernels the VAE decoders use (three
+        # MFMA passes over hi / lo planes, float32 accumulation), float32 norms / activations / softmax (unet_f32.py,
+        # flux/clip.py `_call_f32`), float32 latents and sampler.  It is the arithmetic path, not a tuned one (3x the MFMA work).
+        # storage="bfloat16" (or FLUXHIP_SD_STORAGE=bfloat16) remains as the explicit, NAMED opt-in to bf16 storage: same kernels
+        # as float16, float32 range, 8-bit significand (rel-L2 7e-3 against float32 on the full-size UNet where float16
+        # measures ~1e-3).  Nothing narrower than what the caller asked for runs silently.  The VAE decode is float32-faithful
+        # in every mode.
         import os
         if float16:
             # an explicit float16=True wins over the FLUXHIP_SD_STORAGE environment default (flux_app.py always passes it: the
             # server must keep building its pipelines with that variable exported); only an explicit storage= can contradict it
             if storage not in (None, "float16"):
                 raise ValueError(f"float16=True stores IEEE half; storage='{storage}' contradicts it")
-            storage = "float16"
+            self.dtype = torch.float16
         else:
-            storage = storage or os.environ.get("FLUXHIP_SD_STORAGE")
-        if float16:
-            pass
-        elif storage != "bfloat16":
-            raise NotImplementedError(
-                "StableDiffusion(float16=False) is the reference's float32 UNet / text-encoder arithmetic "
-                "(stable_diffusion/__init__.py:18-23), which this engine does not implement.  Pass float16=True (IEEE half on "
-                "the f16 matrix cores: the reference's own float16 mode, what flux_app.py uses), or opt into bfloat16 storage "
-                "explicitly with storage='bfloat16' / FLUXHIP_SD_STORAGE=bfloat16 (8-bit significand: NARROWER than float32, "
-                "rel-L2 7e-3 on the full-size UNet).  The VAE decode is float32-faithful in every mode.")
-        self.dtype = torch.float16 if float16 else torch.bfloat16
+            storage = storage or os.environ.get("FLUXHIP_SD_STORAGE") or "float32"
+            if storage not in ("float32", "bfloat16"):
+                raise ValueError(f"float16=False computes in float32 (storage='float32', the default) or, by explicit request, "
+                                 f"with bfloat16 storage; got storage='{storage}'")
+            self.dtype = torch.float32 if storage == "float32" else torch.bfloat16
         self.float16 = bool(float16)
         self.device = _lib.bind_device(device)
         self.use_graph = use_graph
         self._graphs = OrderedDict()
         self.shard = None
         self.diffusion_config = load_diffusion_config(model)
-        self.unet = load_unet(model, float16, device=device)
-        self._towers = {"text_encoder": _LazyTower(lambda: load_text_encoder(model, float16, device=device))}
+        self.unet = load_unet(model, float16, device=device, dtype=self.dtype)
+        self._towers = {"text_encoder": _LazyTower(lambda: load_text_encoder(model, float16, device=device, dtype=self.dtype))}
         self.autoencoder = load_autoencoder(model, False, device=device)
         self.sampler = SimpleEulerSampler(self.diffusion_config)
         self._set_sampler_dtype()
@@ -295,7 +292,7 @@ class StableDiffusionXL(StableDiffusion):
         self._set_sampler_dtype()
         self._towers = {"text_encoder_1": self._towers["text_encoder"],
                         "text_encoder_2": _LazyTower(lambda: load_text_encoder(model, float16, model_key="text_encoder_2",
-                                                                               device=device))}
+                                                                               device=device, dtype=self.dtype))}
         self.tokenizer_1 = self.tokenizer
         del self.tokenizer
         self.tokenizer_2 = load_tokenizer(model, merges_key="tokenizer_2_merges", vocab_key="tokenizer_2_vocab")

@@ -133,9 +133,11 @@ def _load_mapped(mapper, path):
     return out
 
 
-def load_unet(key: str = _DEFAULT_MODEL, float16: bool = False, device="cuda", seed: int = 0) -> UNetModel:
+def load_unet(key: str = _DEFAULT_MODEL, float16: bool = False, device="cuda", seed: int = 0, dtype=None) -> UNetModel:
+    """dtype (an addition): the model's arithmetic when it is not implied by float16 - torch.float32 = the reference's
+    float32 (what float16=False means there, model_io.py:171-174), torch.bfloat16 = the bf16-storage opt-in."""
     _check_key(key, "load_unet")
-    model = UNetModel(_MODELS[key]["unet_config"], device=device, dtype=torch.float16 if float16 else torch.bfloat16)
+    model = UNetModel(_MODELS[key]["unet_config"], device=device, dtype=dtype or (torch.float16 if float16 else torch.bfloat16))
     path = _weights_file(key, _MODELS[key]["unet"])
     if path:
         model.load_weights(_load_mapped(map_unet_weights, path))
@@ -176,7 +178,7 @@ _TEXT_CONFIGS = {
 
 
 def load_text_encoder(key: str = _DEFAULT_MODEL, float16: bool = False, model_key: str = "text_encoder",
-                      config_key: Optional[str] = None, device="cuda", seed: int = 21) -> CLIPTextModel:
+                      config_key: Optional[str] = None, device="cuda", seed: int = 21, dtype=None) -> CLIPTextModel:
     """The real CLIP text transformer on libfluxhip (flux/clip.py): config from <SD_WEIGHTS_DIR>/<key>/<model_key>/
     config.json when present (else the built-in hub values), weights from .../model.safetensors through
     map_clip_text_encoder_weights; random init (with a warning) when no checkpoint is configured."""
@@ -188,7 +190,7 @@ def load_text_encoder(key: str = _DEFAULT_MODEL, float16: bool = False, model_ke
             config = CLIPTextModelConfig.from_dict(json.load(f))
     else:
         config = CLIPTextModelConfig(**_TEXT_CONFIGS[(key, model_key)])
-    model = CLIPTextModel(config, device=device, dtype=torch.float16 if float16 else torch.bfloat16)
+    model = CLIPTextModel(config, device=device, dtype=dtype or (torch.float16 if float16 else torch.bfloat16))
     path = _weights_file(key, f"{model_key}/model.safetensors")
     if path:
         model.load_weights(_load_mapped(map_clip_text_encoder_weights, path))

@@ -9,8 +9,9 @@ flattened names, i.e. exactly what model_io.map_unet_weights produces.  The body
     (V^T = Wv y^T) so the head_dim-64 flash attention needs no transpose pass; out-projection +
     residual, GEGLU (linear1(y) * gelu(linear2(y))) and linear3 + residual are GEMM epilogues;
   * skip concats are one copy kernel; down/upsampling are strided / upsample-fused conv loaders.
-Precision: the reference runs this model in fp16 (flux_app.py:77-79) or fp32; here it is bf16 storage
-with fp32 accumulation (stated in tests/test_sd_gpu.py).
+Precision: the reference runs this model in float16 (float16=True, flux_app.py:77-79) or float32 (its default).  dtype
+torch.float16: IEEE-half storage on the f16 matrix cores; torch.float32: float32 arithmetic on the float32-faithful
+split-bf16 kernels (unet_f32.py); torch.bfloat16: bf16 storage, an explicit opt-in of the pipelines.
 """
 from __future__ import annotations
 
@@ -138,9 +139,13 @@ class UNetModel:
         """dtype: the 16-bit storage type of weights and activations — torch.float16 is the reference's arithmetic under
         float16=True (stable_diffusion/__init__.py:20-27; v_mfma_f32_16x16x32_f16, fp32 accumulate / norms / softmax),
         torch.bfloat16 the range-safe default of this path."""
-        if dtype not in (BF16, torch.float16):
-            raise ValueError("UNetModel dtype must be torch.bfloat16 or torch.float16")
+        if dtype not in (BF16, torch.float16, torch.float32):
+            raise ValueError("UNetModel dtype must be torch.bfloat16, torch.float16 or torch.float32")
         self.dtype = dtype
+        # torch.float32: the reference's arithmetic under its DEFAULT float16=False - float32 master parameters, the forward on
+        # the float32-faithful split-bf16 kernels (unet_f32.py)
+        self.x3 = dtype == torch.float32
+        self._x3: Dict[str, torch.Tensor] = {}
         self.config = config
         if torch.device(device).type != "cuda":
             raise FluxHipError("UNetModel needs a HIP device: there is no CPU fallback for the denoise path")
@@ -152,8 +157,6 @@ class UNetModel:
         self._params = {k: torch.empty(*shp, dtype=self.dtype, device=self.device)
                         for k, shp in unet_weight_shapes(config).items()}
         self._fused: Dict[str, torch.Tensor] = {}
-        self._side = None
-        self._vt_fork = os.environ.get("FLUXHIP_UNET_VT_FORK", "0") == "1"
         self.down, self.up = block_plan(config)
         self._sig_t = sinusoidal_sigmas(config.block_out_channels[0]).to(self.device)
         self._sig_add = (sinusoidal_sigmas(config.addition_time_embed_dim).to(self.device)
@@ -196,6 +199,12 @@ class UNetModel:
         """Derived weight layouts: [q;k] projection fused, conv_in input channels zero-padded to 64 (one K-step of
         the implicit-GEMM loader, so the layer runs on the MFMA path; the extra products are exact zeros)."""
         P, F = self._params, {}
+        if self.x3:
+            from .unet_f32 import UNetF32, build_operands
+            self._x3 = build_operands(P)
+            self._f32 = UNetF32(self)
+            self._fused = {}
+            return self
         for k in list(P):
             if k.endswith(".attn1.query_proj.weight"):
                 b = k[: -len(".query_proj.weight")]
@@ -255,6 +264,8 @@ class UNetModel:
         the concatenated key weights -> K [B,Tkp,sum C] and one batched GEMM V^T[b] = Wv_all mem[b]^T -> [B,sum C,Tkpad]
         (padded keys stay zero).  A pipeline computes this once per job and passes it to every step (`text_kv=`);
         `out` = a dict from an earlier call to overwrite in place (static buffers of a captured step graph)."""
+        if self.x3:        # the float32 forward projects K / V^T per layer from the encoder states it is given
+            return out if out is not None else {}
         B, Tkp, enc = mem.shape
         Tkpad = (Tkp + 63) // 64 * 64
         kv = out if out is not None else {"Tkp": Tkp, "Tkpad": Tkpad}
@@ -286,23 +297,13 @@ class UNetModel:
         if kv is None:
             Tkpad = (N + 63) // 64 * 64
             vt = torch.zeros(B, C, Tkpad, dtype=self.dtype, device=dev) if Tkpad != N else torch.empty(B, C, N, dtype=self.dtype, device=dev)
-            # The [q;k] projection and V^T = Wv n^T read the same LayerNorm output and nothing of each other: with
-            # FLUXHIP_UNET_VT_FORK=1 the V^T GEMM is forked onto a side stream (a parallel branch of the captured step graph) and
-            # joined in front of the attention, so that its 160 tiles run beside the [q;k] launch's partial second round
-            cur = torch.cuda.current_stream()
-            fork = self._vt_fork and B * N >= 2048
-            if fork:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=dev)
-                self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side if fork else cur):
-                # V^T[b] = Wv n[b]^T : A = Wv (shared), "W" operand = the rows of batch b
-                ops.gemm(make_gemm_desc([dict(A=W[f"{p}.value_proj.weight"].data_ptr(), W=n.data_ptr(), C=vt.data_ptr(),
-                                              a_bstride=0, w_bstride=N * C, c_bstride=C * Tkpad, M=C)],
-                                        B, N, C, C, Tkpad), f16)
+            # V^T[b] = Wv n[b]^T : A = Wv (shared), "W" operand = the rows of batch b
+            # (round 6: this launch forked onto a side stream beside the [q;k] projection - both read the same LayerNorm output and
+            #  nothing of each other - measured 34.9 ms per UNet step against 34.4 in line, profiles/r06_negative_experiments.json)
+            ops.gemm(make_gemm_desc([dict(A=W[f"{p}.value_proj.weight"].data_ptr(), W=n.data_ptr(), C=vt.data_ptr(),
+                                          a_bstride=0, w_bstride=N * C, c_bstride=C * Tkpad, M=C)],
+                                    B, N, C, C, Tkpad), f16)
             qk = ops.linear(n, self._fused[f"{p}.qk"])                       # [B,N,2C]
-            if fork:
-                cur.wait_stream(self._side)
             ops.attention_strided(qk, qk[..., C:], vt, o, B, H, 64, N, Tk, Tkpad, (N * 2 * C, 64, 2 * C), (N * 2 * C, 64, 2 * C), C,
                                   64 ** -0.5)
         else:
@@ -360,6 +361,8 @@ class UNetModel:
     # ------------------------------------------------------------------ forward
     def pad_encoder_states(self, encoder_x: torch.Tensor) -> torch.Tensor:
         """encoder states zero-padded to a multiple of 8 tokens (GEMM N granularity); padded keys are masked."""
+        if self.x3:
+            return encoder_x
         B, S, e = encoder_x.shape
         mem = torch.zeros(B, (S + 7) // 8 * 8, e, dtype=self.dtype, device=self.device)
         mem[:, :S].copy_(encoder_x)
@@ -370,6 +373,8 @@ class UNetModel:
         """UNetModel.__call__ (unet.py:403-460). x [B,h,w,4] NHWC, timestep [B], encoder_x [B,S,enc]."""
         if attn_mask is not None or encoder_attn_mask is not None:
             raise NotImplementedError("masks are always None on the reference's path (unet.py:403-411)")
+        if self.x3:
+            return self._f32(x, timestep, encoder_x, text_time)
         cfg, W = self.config, self._params
         x = x.to(self.dtype).contiguous()
         B = x.shape[0]

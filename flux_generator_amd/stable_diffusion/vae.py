@@ -98,11 +98,15 @@ class Autoencoder:
         cfg, S = self.config, self._store
         # float16 latents (float16=True pipelines) stay float16 into the fp32-faithful path: the reference promotes them to the
         # VAE's float32 after the division by the scaling factor (vae.py:256-258); the bf16-storage opt-in takes bf16
-        z = (z if (fp32 and z.dtype == torch.float16) else z.to(BF16)).contiguous()
+        # float32 latents (float16=False pipelines) go in as they are: the whole decode is then the reference's float32
+        z = (z if (fp32 and z.dtype in (torch.float16, torch.float32)) else z.to(BF16)).contiguous()
         cin = cfg.latent_channels_in
         cpad = (cin + 63) // 64 * 64
         # z / scaling_factor -> post_quant_proj (vae.py:256-258), output zero-padded to 64 channels
-        if fp32:
+        if fp32 and z.dtype == torch.float32:
+            x = ops.pixel_linear_x3_f32in(z, S.get("post_quant_proj.weight", "f32"), S.get("post_quant_proj.bias", "f32"), cpad,
+                                          self.scaling_factor)
+        elif fp32:
             x = ops.pixel_linear_x3(z, S.get("post_quant_proj.weight", "f32"), S.get("post_quant_proj.bias", "f32"), cpad,
                                     self.scaling_factor)
         else:

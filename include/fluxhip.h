@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define FLUXHIP_ABI_VERSION 8
+#define FLUXHIP_ABI_VERSION 9
 
 int fluxhip_abi_version(void);
 /* "gfx950" — the only architecture this library is built for. */
@@ -489,6 +489,39 @@ int fluxhip_embedding_f16(const void* idx, const void* table, const void* pos, v
                           int D, int T, int V, void* stream);
 int fluxhip_pixel_linear_x3_f16in(const void* x, const void* w, const void* bias, void* out, int64_t out_lo,
                                   int64_t npix, int Cin, int Cout, int Cpad, float in_div, void* stream);
+
+/* ---- float32 arithmetic for the stable_diffusion/ UNet and text towers (ABI 9) ------------------------------------
+ * `StableDiffusion(model)` / `StableDiffusionXL(model)` with the reference's DEFAULT float16=False run UNet and CLIP in
+ * float32 (stable_diffusion/stable_diffusion/__init__.py:19-25, model_io.py:171-174).  Here that arithmetic is the
+ * float32-faithful "bf16x3" form the VAE decoders use: a float32 tensor is a SPLIT tensor (hi + lo bf16 planes, addressed
+ * as hi pointer + offset of the lo plane in elements), every Linear / conv is fluxhip_gemm_x3 / fluxhip_conv2d_x3 (three
+ * MFMA passes, float32 accumulation), GroupNorm is fluxhip_groupnorm_silu_x3, and the entry points below are the rest of
+ * a ResnetBlock2D / TransformerBlock / CLIP layer in float32 on split tensors.  gamma / beta / tables are float32.
+ *   fluxhip_layernorm_x3        nn.LayerNorm(D) rows (unet.py:45,50,57; clip.py), D % 4 == 0, D <= 4096
+ *   fluxhip_act_x3              mode 0 SiLU, 1 exact-erf GELU, 2 quick-GELU (x sigmoid(1.702 x)), 3 GEGLU: out[r, c] =
+ *                               a[r, c] * gelu(a[r, gate_off + c]) (unet.py:74-78 with linear1 / linear2 as one GEMM); libm exp / erf
+ *   fluxhip_addvec_x3           x[b, p, c] += v[b, c] in place (the time-embedding add of ResnetBlock2D, unet.py:158-160)
+ *   fluxhip_sincos_embed_x3     [cos(x sig) | sin(x sig)] (unet.py:283-313), float32 in, split out
+ *   fluxhip_axpbypcz_f32        out = ca x + cb y + cc z on float32 latents (sampler.py:76-105, CFG __init__.py:77-78);
+ *                               coef != NULL: (ca, cb, cc) read from a float32[3] device buffer
+ *   fluxhip_softmax_rows_masked_x3   softmax(scale * s[r, :cols]) of float32 logits -> split probabilities [rows][ld];
+ *                               causal_T > 0: row r sees columns [0, r % causal_T] (clip.py:127-137); other columns are zeros
+ *   fluxhip_embedding_x3        out[i] = table[idx[i]] (+ pos[i % T]) from float32 tables (clip.py:83-84,134-135)
+ *   fluxhip_pixel_linear_x3_f32in    fluxhip_pixel_linear_x3 on float32 latents (vae.py:256-258) */
+int fluxhip_layernorm_x3(const void* x, int64_t x_lo, const float* gamma, const float* beta, void* out, int64_t out_lo,
+                         int64_t rows, int D, float eps, void* stream);
+int fluxhip_act_x3(const void* a, int64_t a_lo, int64_t lda, void* out, int64_t out_lo, int64_t ldo, int64_t rows, int cols,
+                   int mode, int gate_off, void* stream);
+int fluxhip_addvec_x3(void* x, int64_t x_lo, const void* v, int64_t v_lo, int B, int64_t hw, int C, void* stream);
+int fluxhip_sincos_embed_x3(const float* x, const float* sig, void* out, int64_t out_lo, int n, int half, void* stream);
+int fluxhip_axpbypcz_f32(const float* x, const float* y, const float* z, float* out, int64_t n, float ca, float cb, float cc,
+                         const float* coef, void* stream);
+int fluxhip_softmax_rows_masked_x3(const float* s, void* p, int64_t p_lo, int64_t rows, int cols, int ld, float scale,
+                                   int causal_T, void* stream);
+int fluxhip_embedding_x3(const int* idx, const float* table, const float* pos, void* out, int64_t out_lo, int64_t n, int D,
+                         int T, int V, void* stream);
+int fluxhip_pixel_linear_x3_f32in(const float* x, const float* w, const float* bias, void* out, int64_t out_lo, int64_t npix,
+                                  int Cin, int Cout, int Cpad, float in_div, void* stream);
 
 #ifdef __cplusplus
 }

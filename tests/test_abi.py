@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_loader_checks_abi_and_arch():
     from flux_generator_amd import _lib
     lib = _lib.load()
-    assert lib.fluxhip_abi_version() == 8 and lib.fluxhip_arch() == b"gfx950"
+    assert lib.fluxhip_abi_version() == 9 and lib.fluxhip_arch() == b"gfx950"
 
 
 def test_gemm_desc_layout_matches_header():

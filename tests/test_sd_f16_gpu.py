@@ -387,9 +387,8 @@ def _tiny_sd_zoo(monkeypatch, xl):
 @pytest.mark.parametrize("xl", [True, False])
 def test_pipeline_float16_is_float16_end_to_end(dev, monkeypatch, xl):
     """StableDiffusion[XL](float16=True): UNet, text towers, latents and sampler all float16 (nothing silently bf16), graph ==
-    eager bit for bit, images finite.  float16=False is the reference's FLOAT32 arithmetic (stable_diffusion/__init__.py:18-23),
-    which is not built: the constructor says so instead of computing in something narrower; bfloat16 storage is an explicit,
-    named opt-in (storage="bfloat16")."""
+    eager bit for bit, images finite.  float16=False is the reference's FLOAT32 arithmetic (stable_diffusion/__init__.py:18-23;
+    tests/test_sd_f32_gpu.py); bfloat16 storage is an explicit, named opt-in (storage="bfloat16")."""
     import warnings
     from flux_generator_amd.stable_diffusion import StableDiffusion, StableDiffusionXL
     key = _tiny_sd_zoo(monkeypatch, xl)
@@ -399,13 +398,11 @@ def test_pipeline_float16_is_float16_end_to_end(dev, monkeypatch, xl):
         sd = cls(key, float16=True)
         sd_eager = cls(key, float16=True, use_graph=False)
         sd_bf = cls(key, float16=False, storage="bfloat16")
-    with pytest.raises(NotImplementedError, match="float32"):
-        cls(key, float16=False)
-    with pytest.raises(NotImplementedError, match="float32"):
-        cls(key)                                              # the reference's default constructor
     with pytest.raises(ValueError):
         cls(key, float16=True, storage="bfloat16")
-    # the environment default never contradicts an explicit float16=True (flux_app.py always passes it)
+    # float16=False (the reference's default constructor) is its float32 arithmetic (tests/test_sd_f32_gpu.py); the environment
+    # default FLUXHIP_SD_STORAGE=bfloat16 selects bf16 storage for it and never contradicts an explicit float16=True
+    # (flux_app.py always passes it)
     monkeypatch.setenv("FLUXHIP_SD_STORAGE", "bfloat16")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
