@@ -651,7 +651,7 @@ def test_gemm_picker_keeps_the_flux_plan(dev):
     """The tile picker's time model was refitted on 111 shapes in round 3 (csrc/gemm.hip, kCands); the choices for the six
     block GEMMs of the batch-1 Flux plan were established IN SITU (tools/plan_sweep.py) and are the constraint of that fit:
     256x192 for qkv, 128x128 for attn.proj, 256x256 for mlp0, 256x224 for linear1, 256x192 split-K 3 (reduce-scatter) for the
-    two K >= 12288 projections.  Also: the mid-sized SDXL projection the old model mis-ranked now gets 128x256."""
+    two K >= 12288 projections.  Also: the mid-sized SDXL projection the old model mis-ranked gets the 128x160 tile of round 6."""
     import ctypes
     from flux_generator_amd import _lib
     from flux_generator_amd.ops import make_gemm_desc
@@ -668,7 +668,7 @@ def test_gemm_picker_keeps_the_flux_plan(dev):
     assert pick([256, 1024], 3072, 12288) == (51, 3)
     assert pick([1280], 21504, 3072) == (50, 1)
     assert pick([1280], 3072, 15360) == (51, 3)
-    assert pick([4096], 1280, 1280) == (55, 1)
+    assert pick([4096], 1280, 1280) == (57, 1)       # round 6: 128x160 - 1280 = 8 x 160, 256 tiles (128x256 before: 160 tiles)
 
 
 @pytest.mark.parametrize("M,C", [(4096, 1280), (600, 320), (16384, 640), (130, 64)])
