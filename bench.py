@@ -334,7 +334,7 @@ def parity_full_size_record():
     """The committed full-size parity numbers (not re-measured by the bench: the oracle forwards take minutes of host time):
     what `pytest tests/test_full_size_parity_gpu.py` measured for this tree on a GPU box, copied to profiles/ by the round's
     profile script.  Every number is against an oracle whose parity with the MLX reference is UNPINNED (oracle/UNVERIFIED.md)."""
-    for name in ("r05_parity_full_size.json", "r04_parity_full_size.json"):
+    for name in ("r06_parity_full_size.json", "r05_parity_full_size.json", "r04_parity_full_size.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
