@@ -186,10 +186,7 @@ class CLIPTextModel:
         tok = tok.to(self.device).contiguous()
         dev = self.device
         h = ops.embedding_x3(tok, P["token_embedding.weight"], X["pos"][:Np].contiguous())            # [2,B,Np,D]
-        o = torch.empty(2, B, Np, D, dtype=BF16, device=dev)
-        vt = torch.zeros(2, D, Tpad, dtype=BF16, device=dev)
-        s = torch.empty(H, Np, Tpad, dtype=torch.float32, device=dev)
-        pm = torch.empty(2, H, Np, Tpad, dtype=BF16, device=dev)
+        vt = torch.zeros(2, B, D, Tpad, dtype=BF16, device=dev)
         act = ops.ACT_QUICK_GELU if c.hidden_act == "quick_gelu" else ops.ACT_GELU_ERF
         hs = []
         for i in range(c.num_layers):
@@ -198,13 +195,9 @@ class CLIPTextModel:
             y = ops.layernorm_x3(h, P[f"{p}.layer_norm1.weight"], P[f"{p}.layer_norm1.bias"])
             q = ops.linear_x3(y, X[f"{a}.query_proj.weight"], P[f"{a}.query_proj.bias"])
             k = ops.linear_x3(y, X[f"{a}.key_proj.weight"], P[f"{a}.key_proj.bias"])
-            k_hm = k.view(2, B, Np, H, 64).permute(0, 1, 3, 2, 4).contiguous()                       # [2,B,H,Np,64]: a copy, no arithmetic
-            for b in range(B):
-                ops.gemm_x3_batched(X[f"{a}.value_proj.weight"], y[:, b], vt, D, Np, D, D, Tpad, 1, 0, 0, 0,
-                                    bias=P[f"{a}.value_proj.bias"], row_bias=True)
-                ops.gemm_x3_batched(q[:, b], k_hm[:, b], s, Np, Np, 64, D, Tpad, H, 64, Np * 64, Np * Tpad, out_f32=True)
-                ops.softmax_rows_masked_x3(s, 64 ** -0.5, pm, cols=Np, causal_T=Np)
-                ops.gemm_x3_batched(pm, vt, o[:, b], Np, 64, Tpad, Tpad, D, H, Np * Tpad, 64 * Tpad, 64)
+            ops.gemm_x3_batched(X[f"{a}.value_proj.weight"], y, vt, D, Np, D, D, Tpad, B, 0, Np * D, D * Tpad,
+                                bias=P[f"{a}.value_proj.bias"], row_bias=True)
+            o = ops.attention_x3(q, k, vt, H, Np, 64 ** -0.5, causal=True)
             h = ops.linear_x3(o, X[f"{a}.out_proj.weight"], P[f"{a}.out_proj.bias"], res=h)
             y = ops.layernorm_x3(h, P[f"{p}.layer_norm2.weight"], P[f"{p}.layer_norm2.bias"])
             y = ops.act_x3(ops.linear_x3(y, X[f"{p}.linear1.weight"], P[f"{p}.linear1.bias"]), act)

@@ -914,3 +914,33 @@ def gemm_x3_batched(A: torch.Tensor, W: torch.Tensor, C: torch.Tensor, M: int, N
     d.a_bstride, d.w_bstride, d.c_bstride = a_bstride, w_bstride, c_bstride
     d.epi, d.row_bias, d.out_f32, d.tile_cfg, d.alpha = EPI_BIAS, int(row_bias), int(out_f32), 0, alpha
     _check(_lib.load().fluxhip_gemm_x3(d, _stream()), "fluxhip_gemm_x3")
+
+
+def attention_x3(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, H: int, Tk: int, scale: float, causal: bool = False,
+                 max_logit_bytes: int = 1 << 30) -> torch.Tensor:
+    """Multi-head attention (head_dim 64) in float32 arithmetic on split tensors, ALL images and heads per launch:
+    q [2,B,N,C] and k [2,B,Tkp,C] token-major projections, vt [2,B,C,Tkpad] = V transposed (zero beyond Tkp); returns
+    o [2,B,N,C].  Q and K are copied head-major once ([B,H,T,64]: a permutation, no arithmetic) so that (image, head) is ONE
+    batch index with uniform strides; then logits Q_h K_h^T (float32 [B*H, N, Tkpad]), float32 softmax over the first Tk keys
+    (causal: row t sees keys [0, t]) with split probabilities, P_h V_h^T (the V^T image of (b, h) sits at (b H + h) * 64 * Tkpad
+    already), and the heads copied back side by side.  Images are processed in chunks whose logits stay under max_logit_bytes."""
+    _split_ok(q, "q"); _split_ok(k, "k"); _split_ok(vt, "vt")
+    _, B, N, C = q.shape
+    Tkp, Tkpad = k.shape[2], vt.shape[3]
+    if C != 64 * H or k.shape[3] != C or vt.shape[2] != C or Tkpad % 64 or Tkp > Tkpad or Tkp % 4:
+        raise FluxHipError("attention_x3: head_dim 64, k [2,B,Tkp,C], vt [2,B,C,Tkpad] with Tkpad % 64 == 0 and Tkp % 4 == 0")
+    dev = q.device
+    o = torch.empty(2, B, N, C, dtype=BF16, device=dev)
+    nb = max(1, min(B, max_logit_bytes // max(1, H * N * Tkpad * 4)))
+    s = torch.empty(nb * H, N, Tkpad, dtype=F32, device=dev)
+    pm = torch.empty(2, nb * H, N, Tkpad, dtype=BF16, device=dev)
+    for b0 in range(0, B, nb):
+        n = min(nb, B - b0)
+        q_hm = q[:, b0:b0 + n].reshape(2, n, N, H, 64).permute(0, 1, 3, 2, 4).contiguous()        # [2,n,H,N,64]
+        k_hm = k[:, b0:b0 + n].reshape(2, n, Tkp, H, 64).permute(0, 1, 3, 2, 4).contiguous()      # [2,n,H,Tkp,64]
+        o_hm = torch.empty(2, n, H, N, 64, dtype=BF16, device=dev)
+        gemm_x3_batched(q_hm, k_hm, s, N, Tkp, 64, 64, Tkpad, n * H, N * 64, Tkp * 64, N * Tkpad, out_f32=True)
+        softmax_rows_masked_x3(s[: n * H], scale, pm[:, : n * H], cols=Tk, causal_T=N if causal else 0)
+        gemm_x3_batched(pm, vt[:, b0:b0 + n], o_hm, N, 64, Tkpad, Tkpad, 64, n * H, N * Tkpad, 64 * Tkpad, N * 64)
+        o[:, b0:b0 + n].copy_(o_hm.permute(0, 1, 3, 2, 4).reshape(2, n, N, C))
+    return o

@@ -6,14 +6,12 @@ arrays).  Same launch structure as the 16-bit path of unet.py, on the float32-fa
     `fluxhip_conv2d_x3` (three MFMA passes over the planes, float32 accumulation, float32 bias / residual);
   * GroupNorm + SiLU, LayerNorm, the GEGLU product, SiLU of the time embedding, the per-image time-embedding add and the
     sinusoidal embeddings are float32 kernels on split tensors (include/fluxhip.h, "ABI 9");
-  * multi-head attention: K is projected HEAD-MAJOR by one H-batched GEMM per image (the weight rows of head h are a
-    contiguous block), V transposed, the logits Q_h K_h^T of all heads by one H-batched GEMM with float32 output
-    [H, N, Tkpad], a float32 softmax with split probabilities, and P_h V_h^T by a third H-batched GEMM that writes the
-    heads side by side into the [N, C] output — the per-(image, head) products of nn.MultiHeadAttention (unet.py:46-54),
-    never a 16-bit logit or probability.
+  * multi-head attention (`ops.attention_x3`): Q and K copied head-major, V projected transposed, then ONE batched
+    float32-faithful GEMM for the logits Q_h K_h^T of every (image, head) with float32 output [B*H, N, Tkpad], a float32
+    softmax with split probabilities, and one for P_h V_h^T — the per-(image, head) products of nn.MultiHeadAttention
+    (unet.py:46-54), never a 16-bit logit or probability.
 
-This is the arithmetic path, not a tuned one: 3x the MFMA work of the 16-bit kernels, one launch group per image in the
-attention, no captured-graph specialisation beyond what the pipeline does.  tests/test_sd_f32_gpu.py compares it with the
+This is the arithmetic path, not a tuned one: 3x the MFMA work of the 16-bit kernels, unfused norms / activations, no captured-graph specialisation beyond what the pipeline does.  tests/test_sd_f32_gpu.py compares it with the
 float32 oracle (oracle/sd_oracle.py): tiny UNet <= 1e-4, full-width blocks <= 1e-3."""
 from __future__ import annotations
 
@@ -96,23 +94,12 @@ class UNetF32:
         src = n if mem is None else mem
         Tkp, Kd = src.shape[2], src.shape[3]
         Tkpad = (Tkp + 63) // 64 * 64
-        q, ldq = ops.linear_x3(n, X[f"{p}.query_proj.weight"], None), C                       # token-major [2,B,N,C]
-        wk, wv = X[f"{p}.key_proj.weight"], X[f"{p}.value_proj.weight"]
-        o = torch.empty(2, B, N, C, dtype=BF16, device=dev)
-        k_hm = torch.empty(2, H, Tkp, 64, dtype=BF16, device=dev)
-        vt = torch.zeros(2, C, Tkpad, dtype=BF16, device=dev)                               # padded key columns stay zero
-        s = torch.empty(H, N, Tkpad, dtype=F32, device=dev)
-        pm = torch.empty(2, H, N, Tkpad, dtype=BF16, device=dev)
-        for b in range(B):
-            # K head-major: head h = rows [64 h, 64 h + 64) of the key weight (w_bstride), written to k_hm[h] (c_bstride)
-            ops.gemm_x3_batched(src[:, b], wk, k_hm, Tkp, 64, Kd, Kd, 64, H, 0, 64 * Kd, Tkp * 64)
-            # V^T = Wv src[b]^T: [C, Tkp] into [C, Tkpad]
-            ops.gemm_x3_batched(wv, src[:, b], vt, C, Tkp, Kd, Kd, Tkpad, 1, 0, 0, 0)
-            # logits of every head: Q_h (column block h of the token-major projection) x K_h^T -> float32 [H, N, Tkpad]
-            ops.gemm_x3_batched(q[:, b], k_hm, s, N, Tkp, 64, ldq, Tkpad, H, 64, Tkp * 64, N * Tkpad, out_f32=True)
-            ops.softmax_rows_masked_x3(s, 64 ** -0.5, pm, cols=Tk)
-            # P_h V_h^T, the heads side by side in the token-major output
-            ops.gemm_x3_batched(pm, vt, o[:, b], N, 64, Tkpad, Tkpad, C, H, N * Tkpad, 64 * Tkpad, 64)
+        q = ops.linear_x3(n, X[f"{p}.query_proj.weight"], None)                              # token-major [2,B,N,C]
+        k = ops.linear_x3(src, X[f"{p}.key_proj.weight"], None)                              # [2,B,Tkp,C]
+        # V^T[b] = Wv src[b]^T for every image in one launch: A = Wv shared, "W" operand = the rows of image b
+        vt = torch.zeros(2, B, C, Tkpad, dtype=BF16, device=dev)                            # padded key columns stay zero
+        ops.gemm_x3_batched(X[f"{p}.value_proj.weight"], src, vt, C, Tkp, Kd, Kd, Tkpad, B, 0, Tkp * Kd, C * Tkpad)
+        o = ops.attention_x3(q, k, vt, H, Tk, 64 ** -0.5)
         return ops.linear_x3(o, X[f"{p}.out_proj.weight"], W[f"{p}.out_proj.bias"], res=y)
 
     def transformer(self, p: str, H: int, layers: int, x: torch.Tensor, mem: torch.Tensor, Tk: int) -> torch.Tensor:

@@ -114,6 +114,30 @@ def test_gemm_x3_batched_is_per_head_attention(dev, N, Tk, H):
     assert e < 3e-5
 
 
+@pytest.mark.parametrize("B,N,Tk,H,causal", [(3, 128, 80, 2, False), (2, 80, 80, 4, True), (16, 256, 77, 20, False)])
+def test_attention_x3_all_images_and_heads_per_launch(dev, B, N, Tk, H, causal):
+    """ops.attention_x3 - what UNetF32.mha and CLIPTextModel._call_f32 call: (image, head) as one batch index of two batched
+    float32-faithful GEMMs around the float32 softmax (key count / causal mask), images chunked by the logits' size."""
+    from flux_generator_amd import ops
+    C = 64 * H
+    Tkp = (Tk + 7) // 8 * 8
+    Tkpad = (Tkp + 63) // 64 * 64
+    q, k, v = frnd(B, N, C, seed=1), frnd(B, Tkp, C, seed=2), frnd(B, Tkp, C, seed=3)
+    qs, ks, vs = sp(q, dev), sp(k, dev), sp(v, dev)
+    vt = torch.zeros(2, B, C, Tkpad, dtype=BF, device=dev)
+    vt[..., :Tkp] = vs.transpose(2, 3)
+    hd = lambda t, T_: jn(sp(t, dev)).view(B, T_, H, 64).transpose(1, 2)      # noqa: E731
+    qq, kk, vv = hd(q, N), hd(k, Tkp)[:, :, :Tk], hd(v, Tkp)[:, :, :Tk]
+    logits = qq @ kk.transpose(-1, -2) * 64 ** -0.5
+    if causal:
+        logits = logits.masked_fill(torch.triu(torch.ones(N, Tk, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(logits, -1) @ vv).transpose(1, 2).reshape(B, N, C)
+    for cap in (1 << 30, H * N * Tkpad * 4 * 2):               # one chunk / chunks of two images
+        got = jn(ops.attention_x3(qs, ks, vt, H, Tk, 64 ** -0.5, causal=causal, max_logit_bytes=cap))
+        e = rel_l2(got, ref)
+        assert e < 3e-5, (cap, e)
+
+
 def build_unet_f32(dev, xl, seed=0):
     from flux_generator_amd.stable_diffusion.config import UNetConfig
     from flux_generator_amd.stable_diffusion.unet import UNetModel
