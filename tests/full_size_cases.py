@@ -88,6 +88,30 @@ def c3_forward(case, dev):
                         torch.full((1,), case["guidance"], dtype=BF, device=dev))
 
 
+C3_LOOP_STEPS = 3      # steps of the 28-step schedule the stored loop fixture covers (each oracle step: ~3 min of host time)
+
+
+def c3_loop_case(dev):
+    """Flux-dev 1024 x 1024 through the PRODUCT's own loop (FluxPipeline._denoising_loop: shifted 28-step schedule, hoisted
+    modulation tables, graph replay, Euler kernel): the pipeline's seed-0 flow weights with live modulation, inputs seed 8."""
+    import warnings
+    from flux_generator_amd.flux import FluxPipeline
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe = FluxPipeline("flux-dev")
+    live_modulation(pipe.flow, 15)
+    P = pipe.flow.params
+    inputs = flux_inputs(P, 1, 512, 128, seed=8)
+    return dict(pipe=pipe, P=P, inputs=inputs, guidance=7.0, hash=weight_hash(pipe.flow.parameters()))
+
+
+def c3_loop_forward(case, dev):
+    """The first C3_LOOP_STEPS latents of the 28-step loop."""
+    d = [a.to(dev) for a in case["inputs"]]
+    gen = case["pipe"]._denoising_loop(d[0], d[1], d[2], d[3], d[4], num_steps=28, guidance=case["guidance"])
+    return [next(gen).clone() for _ in range(C3_LOOP_STEPS)]
+
+
 C5_MUTATED_LAYER = "single_blocks.19.linear1"      # the mutation check shifts the E8M0 scales this layer's GELU epilogue emits
 
 

@@ -14,7 +14,7 @@ Inputs are regenerated from their seeds by the tests; nothing under /root/refere
 Also here (moved out of tests/ in round 5 so that the default GPU suite has no skipped tests): the diagnostic
 `which rounding compounds` run of round 4 (fp32 oracle with only the residual stream rounded to bf16 between blocks).
 
-usage (GPU box):  python tools/make_full_size_golden.py [c4] [c3] [c5] [c3live] [c5live] [rounding]      (default: c4 c3 c5)
+usage (GPU box):  python tools/make_full_size_golden.py [c4] [c3] [c5] [c3live] [c5live] [c3loop] [rounding]      (default: c4 c3 c5)
 (`c3live` / `c5live`, round 6: the same cases with O(0.3) modulation - tests/full_size_cases.py - and, for c5, the measured
 effect of the committed mutation: one layer's E8M0 block scales shifted by one exponent)
 Writes tests/golden/full_size/<case>.pt and gpurun_out/full_size_golden/<case>.pt + summary.json (gpurun merges the latter
@@ -89,6 +89,31 @@ def make_c3(dev, live=False):
               meta="Flux-dev init_random(4)" + (" + modulation biases U(-0.5, 0.5) (live_modulation seed 14)" if live else "") +
                    ", inputs seed 2, S=512 L=4096, t=timesteps(28)[1], guidance 7; "
                    "ref_fp32 = fp32 oracle (stored float16), ref_bf16 = oracle in the reference's bf16 arithmetic"))
+
+
+def make_c3loop(dev):
+    """Three steps of Flux-dev's 28-step loop at 1024 x 1024: the product's loop against the float32 oracle loop
+    (flux/flux.py:87-126, flux/sampler.py:22-57)."""
+    case = FC.c3_loop_case(dev)
+    P = case["P"]
+    OP = O.FluxParams(**{k: getattr(P, k) for k in O.FluxParams.__dataclass_fields__})
+    got = FC.c3_loop_forward(case, dev)
+    img, img_ids, txt, txt_ids, vec = case["inputs"]
+    ts = O.timesteps("flux-dev", 28, img.shape[1])
+    assert ts == case["pipe"].sampler.timesteps(28, img.shape[1])
+    W = device_weights(case["pipe"].flow.parameters())
+    x, refs, t0 = img.float(), [], time.perf_counter()
+    for i in range(FC.C3_LOOP_STEPS):
+        pred, _ = oracle_flux(OP, W, (x, img_ids, txt, txt_ids, vec), ts[i], case["guidance"])
+        x = O.euler_step(pred, x, ts[i], ts[i + 1])
+        refs.append(x.clone())
+    m = dict(latents_rel_l2=[rel_l2(g, r) for g, r in zip(got, refs)], timesteps=ts[: FC.C3_LOOP_STEPS + 1],
+             oracle_seconds=time.perf_counter() - t0, host_threads=torch.get_num_threads())
+    print("c3_loop", m, flush=True)
+    SUMMARY["c3_loop"] = m
+    save("c3_dev_t4608_loop3.pt", dict(ref_fp32=[r.to(torch.float16) for r in refs], weight_hash=case["hash"], measured=m,
+                                       meta="FluxPipeline('flux-dev') seed-0 weights + live_modulation(15), inputs seed 8, S=512 L=4096, "
+                                            "guidance 7: latents after steps 1..3 of the 28-step schedule, float32 oracle loop (stored float16)"))
 
 
 def make_c5(dev, live=False):
@@ -181,6 +206,6 @@ if __name__ == "__main__":
     for w in which:
         t0 = time.perf_counter()
         dict(c3=make_c3, c5=make_c5, c4=make_c4, rounding=make_rounding, c3live=lambda d: make_c3(d, True),
-             c5live=lambda d: make_c5(d, True))[w](dev)
+             c5live=lambda d: make_c5(d, True), c3loop=make_c3loop)[w](dev)
         torch.cuda.empty_cache()
         print(f"{w}: {time.perf_counter() - t0:.0f} s", flush=True)
