@@ -155,6 +155,14 @@ def test_sd_checkpoints_load_and_match_oracle(dev, tmp_path, monkeypatch):
     z = torch.randn(1, 8, 8, 4, generator=g).to(BF)
     im = vae.decode_image(z.to(dev))
     assert float((im.cpu() - S.sd_decode(ovae, Wv, z.float())).abs().max()) <= 1.0 / 255
+    # the same files into the float32 model (float16=False, the reference's default: model_io.py:171-174 keeps the checkpoint's
+    # float32): float32 master parameters, float32 arithmetic, float32 latents into the VAE
+    unet32 = model_io.load_unet(key, device=dev, dtype=torch.float32)
+    assert all(v.dtype == torch.float32 for v in unet32.parameters().values())
+    got32 = unet32(x.float().to(dev), t.to(dev), enc.float().to(dev), text_time=(tt[0].float().to(dev), tt[1].to(dev)))
+    assert got32.dtype == torch.float32 and rel_l2(got32, ref) < 1e-4
+    im32 = vae.decode_image(z.float().to(dev))
+    assert float((im32.cpu() - S.sd_decode(ovae, Wv, z.float())).abs().max()) <= 1e-4
 
 
 @pytest.mark.gpu
