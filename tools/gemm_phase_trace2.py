@@ -16,6 +16,8 @@ g = torch.Generator(device=dev).manual_seed(0)
 CASES = {"qkv 1280x9216x3072 bias": (1280, 9216, 3072, ops.EPI_BIAS), "mlp0 1280x12288x3072 gelu": (1280, 12288, 3072, ops.EPI_GELU_TANH),
          "linear1-sized 1280x21504x3072 bias (2 rounds of this tile: 560 tiles)": (1280, 21504, 3072, ops.EPI_BIAS),
          "K=12288 1280x9216x12288 bias": (1280, 9216, 12288, ops.EPI_BIAS)}
+if os.environ.get("TRACE_SHAPES"):      # "name:M:N:K:epi,..." e.g. the SDXL UNet's short-K, multi-round launches
+    CASES = {t.split(":")[0]: tuple(int(v) for v in t.split(":")[1:]) for t in os.environ["TRACE_SHAPES"].split(",")}
 for name, (M, N, K, epi) in CASES.items():
     x = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
     ws = [(torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(4)]
